@@ -1,0 +1,89 @@
+"""ctypes binding of libcorrla_rsvd.so (include/corrla_rsvd.h).  There is no fallback: if the
+HIP library is missing or cannot be loaded, importing the compute API raises."""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libcorrla_rsvd.so")
+
+i64, u64, u32, i32, dbl, flt = C.c_int64, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.c_float
+vp = C.c_void_p
+
+OK, EINVAL, ENOMEM, EHIP, ECOMM, ENUMERIC, ENODEV = range(7)
+OMEGA_ON_DEVICE = 0x1
+UNIQUE_ID_BYTES = 128
+
+
+class Opts(C.Structure):
+    _fields_ = [("struct_size", u32), ("flags", u32), ("seed", u64), ("omega", vp), ("omega_ld", i64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("total_ms", dbl), ("sketch_ms", dbl), ("power_ms", dbl), ("qr_ms", dbl), ("project_ms", dbl),
+                ("small_svd_ms", dbl), ("finalize_ms", dbl), ("qr_passes", i32), ("reserved", i32)]
+
+
+# symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+def _sigs():
+    s = {
+        "corrla_version": (C.c_char_p, []),
+        "corrla_last_error": (C.c_char_p, []),
+        "corrla_device_count": (C.c_int, []),
+        "corrla_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "corrla_ctx_destroy": (None, [vp]),
+        "corrla_ctx_synchronize": (C.c_int, [vp]),
+        "corrla_ctx_get_timings": (C.c_int, [vp, C.POINTER(Timings)]),
+        "corrla_comm_unique_id": (C.c_int, [vp]),
+        "corrla_ctx_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    }
+    for suf, sc in (("f32", flt), ("f64", dbl)):
+        rsvd = [vp, vp, i64, i64, i64, i64, i64, i64, i64, C.POINTER(Opts), vp, i64, vp, vp, i64]
+        s["corrla_rsvd_" + suf] = (C.c_int, rsvd)
+        s["corrla_rsvd_dev_" + suf] = (C.c_int, rsvd)
+        s["corrla_rsvd_sharded_dev_" + suf] = (C.c_int, rsvd)
+        pw = [vp, vp, i64, i64, i64, i64, i64, i64, C.POINTER(Opts), vp, i64]
+        s["corrla_power_iter_" + suf] = (C.c_int, pw)
+        s["corrla_power_iter_dev_" + suf] = (C.c_int, pw)
+        s["corrla_matmul_dev_" + suf] = (C.c_int, [vp, C.c_int, vp, i64, i64, i64, i64, vp, i64, i64, sc, vp, i64])
+        s["corrla_fill_normal_dev_" + suf] = (C.c_int, [vp, vp, i64, i64, i64, i64, u64, i64, i64])
+        s["corrla_time_sketch_dev_" + suf] = (C.c_int, [vp, vp, i64, i64, i64, i64, vp, i64, i64, vp, i64, C.c_int,
+                                                         C.POINTER(dbl)])
+    return s
+
+
+SIGNATURES = _sigs()
+_lib = None
+
+
+class CorrlaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"corrla_rsvd error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load the HIP library.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m corrla_rs_amd.build` (hipcc, gfx950). "
+            "corrla_rs_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != OK:
+        msg = load().corrla_last_error().decode("utf-8", "replace")
+        if code == EINVAL:
+            raise ValueError(f"corrla_rsvd: {msg}")
+        if code == ENOMEM:
+            raise MemoryError(f"corrla_rsvd: {msg}")
+        raise CorrlaError(code, msg)

@@ -1,0 +1,261 @@
+"""Host-side mirror of the reference's RSVD surfaces over the HIP library.
+
+  rsvd(a_mat, n_rank, n_iters, n_oversamples)        <- corrla_rs.rsvd, src/lib_math_utils_py.rs:21-36
+  random_svd(a_mat, omega_rank, n_iter, n_oversamples) <- random_svd.rs:63-66 (Rust name / argument names)
+  power_iter(a_mat, omega_rank, n_iter)              <- random_svd.rs:15-18
+
+Same positional order (rank, iters, oversamples), same return shapes: U (m, k), S (k, 1) -- a 2-D
+column, not 1-D -- and Vt (k, n), column-major in memory like the reference's owned faer `Mat`s
+(numpy: F-ordered).  Additive, keyword-only: `seed`, `omega` (shared sketch, the parity-test hook),
+`ctx`.  numpy inputs take the host-pointer entry points (H2D + D2H around the device path); torch
+CUDA tensors take the device-pointer entry points and return torch tensors on the same device.
+float32 input runs the f32 path (the pyo3 surface is f64-only; anything that is not f32 is
+converted to f64, as PyReadonlyArray2<f64> extraction would require).
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib as L
+
+__all__ = ["Context", "default_context", "rsvd", "random_svd", "power_iter", "algorithmic_flops"]
+
+
+def _is_torch(x):
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class Context:
+    """One device, one stream, one workspace arena (corrla_ctx).  Not thread-parallel: calls on one
+    context serialise, as calls on one faer global thread pool do in the reference."""
+
+    def __init__(self, device=0):
+        self._lib = L.load()
+        h = C.c_void_p()
+        L.check(self._lib.corrla_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.corrla_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- communicator ------------------------------------------------------------------
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+        L.check(L.load().corrla_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = C.create_string_buffer(bytes(unique_id), L.UNIQUE_ID_BYTES)
+        L.check(self._lib.corrla_ctx_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def timings(self):
+        t = L.Timings()
+        L.check(self._lib.corrla_ctx_get_timings(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in t._fields_ if f != "reserved"}
+
+    # ---- helpers -----------------------------------------------------------------------
+    def _opts(self, seed, omega, nt, l, dtype, on_device):
+        if seed is None and omega is None:
+            return None, None
+        o = L.Opts()
+        o.struct_size = C.sizeof(L.Opts)
+        o.seed = int(seed) if seed is not None else 0
+        keep = None
+        if omega is not None:
+            if on_device:
+                import torch
+                om = omega if _is_torch(omega) else torch.as_tensor(np.asarray(omega))
+                om = om.to(device=f"cuda:{self.device}", dtype=dtype)
+                if tuple(om.shape) != (nt, l):
+                    raise ValueError(f"omega must have shape {(nt, l)}, got {tuple(om.shape)}")
+                keep = om.t().contiguous()  # (l, nt) row-major == (nt, l) column-major
+                o.omega = keep.data_ptr()
+                o.flags = L.OMEGA_ON_DEVICE
+            else:
+                om = np.asarray(omega, dtype=dtype)
+                if om.shape != (nt, l):
+                    raise ValueError(f"omega must have shape {(nt, l)}, got {om.shape}")
+                keep = np.asfortranarray(om)
+                o.omega = keep.ctypes.data
+            o.omega_ld = nt
+        return o, keep
+
+    # ---- random_svd ----------------------------------------------------------------------
+    def rsvd(self, a_mat, n_rank, n_iters, n_oversamples, *, seed=None, omega=None):
+        n_rank, n_iters, n_oversamples = int(n_rank), int(n_iters), int(n_oversamples)
+        if _is_torch(a_mat) and a_mat.is_cuda:
+            return self._rsvd_torch(a_mat, n_rank, n_iters, n_oversamples, seed, omega)
+        a = np.asarray(a_mat.detach().cpu().numpy() if _is_torch(a_mat) else a_mat)
+        if a.ndim != 2:
+            raise ValueError("a_mat must be 2-D")
+        if a.dtype != np.float32:
+            a = a.astype(np.float64, copy=False)
+        m, n = a.shape
+        if m == 0 or n == 0:
+            raise ValueError("a_mat must be non-empty")
+        suf = "f32" if a.dtype == np.float32 else "f64"
+        if any(s < 0 for s in a.strides):
+            a = np.ascontiguousarray(a)
+        rs, cs = a.strides[0] // a.itemsize, a.strides[1] // a.itemsize
+        k = n_rank
+        nt = min(m, n)
+        l = min(k + max(n_oversamples, 0), nt)
+        o, keep = self._opts(seed, omega, nt, l, a.dtype, False)
+        kk = max(k, 1)
+        u = np.empty((m, kk), dtype=a.dtype, order="F")
+        s = np.empty((kk, 1), dtype=a.dtype, order="F")
+        vt = np.empty((kk, n), dtype=a.dtype, order="F")
+        fn = getattr(self._lib, "corrla_rsvd_" + suf)
+        L.check(fn(self._h, a.ctypes.data, m, n, rs, cs, k, n_iters, n_oversamples,
+                   C.byref(o) if o is not None else None, u.ctypes.data, m, s.ctypes.data, vt.ctypes.data, kk))
+        del keep
+        return u, s, vt
+
+    def _rsvd_torch(self, a, k, q, p, seed, omega, sharded=False):
+        import torch
+        if a.dim() != 2:
+            raise ValueError("a_mat must be 2-D")
+        if a.dtype not in (torch.float32, torch.float64):
+            a = a.to(torch.float64)
+        if a.device.index != self.device:
+            raise ValueError(f"tensor is on {a.device}, context is on cuda:{self.device}")
+        m, n = a.shape
+        if m == 0 or n == 0:
+            raise ValueError("a_mat must be non-empty")
+        if any(s < 0 for s in a.stride()):
+            a = a.contiguous()
+        rs, cs = a.stride()
+        suf = "f32" if a.dtype == torch.float32 else "f64"
+        nt = n if sharded else min(m, n)
+        l = min(k + max(p, 0), nt)
+        o, keep = self._opts(seed, omega, nt, l, a.dtype, True)
+        kk = max(k, 1)
+        dev = a.device
+        u = torch.empty((kk, m), dtype=a.dtype, device=dev).t()     # (m, k) column-major
+        s = torch.empty((kk, 1), dtype=a.dtype, device=dev)
+        vt = torch.empty((n, kk), dtype=a.dtype, device=dev).t()    # (k, n) column-major
+        torch.cuda.current_stream(dev).synchronize()  # inputs produced on torch's stream are complete
+        name = ("corrla_rsvd_sharded_dev_" if sharded else "corrla_rsvd_dev_") + suf
+        fn = getattr(self._lib, name)
+        L.check(fn(self._h, a.data_ptr(), m, n, rs, cs, k, q, p, C.byref(o) if o is not None else None,
+                   u.data_ptr(), m, s.data_ptr(), vt.data_ptr(), kk))
+        del keep
+        return u, s, vt
+
+    def rsvd_sharded(self, a_local, n_rank, n_iters, n_oversamples, *, seed=None, omega=None):
+        """Row-sharded random_svd: `a_local` holds this rank's rows of the tall
+        matrix as a torch CUDA tensor; returns (U_local, S, Vt) with S, Vt replicated."""
+        return self._rsvd_torch(a_local, int(n_rank), int(n_iters), int(n_oversamples), seed, omega, sharded=True)
+
+    # ---- power_iter ----------------------------------------------------------------------
+    def power_iter(self, a_mat, omega_rank, n_iter, *, seed=None, omega=None):
+        a = np.asarray(a_mat)
+        if a.ndim != 2:
+            raise ValueError("a_mat must be 2-D")
+        if a.dtype != np.float32:
+            a = a.astype(np.float64, copy=False)
+        m, n = a.shape
+        w = int(omega_rank)
+        suf = "f32" if a.dtype == np.float32 else "f64"
+        rs, cs = a.strides[0] // a.itemsize, a.strides[1] // a.itemsize
+        o, keep = self._opts(seed, omega, n, w, a.dtype, False)
+        q = np.empty((m, max(w, 1)), dtype=a.dtype, order="F")
+        fn = getattr(self._lib, "corrla_power_iter_" + suf)
+        L.check(fn(self._h, a.ctypes.data, m, n, rs, cs, w, int(n_iter), C.byref(o) if o is not None else None,
+                   q.ctypes.data, m))
+        del keep
+        return q
+
+    # ---- low-level hooks used by tests / bench ---------------------------------------------
+    def matmul(self, a, x, trans=False, beta=1.0):
+        """res = beta * op(a) @ x on device tensors (par_matmul_helper, mat_utils.rs:20-33)."""
+        import torch
+        m, n = a.shape
+        rs, cs = a.stride()
+        xin, xout = (m, n) if trans else (n, m)
+        assert x.shape[0] == xin and x.dtype == a.dtype
+        l = x.shape[1]
+        xc = x.t().contiguous()  # column-major (xin, l)
+        res = torch.empty((l, xout), dtype=a.dtype, device=a.device)
+        suf = "f32" if a.dtype == torch.float32 else "f64"
+        torch.cuda.current_stream(a.device).synchronize()
+        fn = getattr(self._lib, "corrla_matmul_dev_" + suf)
+        L.check(fn(self._h, 1 if trans else 0, a.data_ptr(), m, n, rs, cs, xc.data_ptr(), xin, l, beta,
+                   res.data_ptr(), xout))
+        return res.t()
+
+    def fill_normal(self, t, seed, row0=0, global_cols=None):
+        """In-place N(0,1) fill of a 2-D device tensor (random_mat_normal, mat_utils.rs:161-175)."""
+        import torch
+        rows, cols = t.shape
+        rs, cs = t.stride()
+        suf = "f32" if t.dtype == torch.float32 else "f64"
+        torch.cuda.current_stream(t.device).synchronize()
+        fn = getattr(self._lib, "corrla_fill_normal_dev_" + suf)
+        L.check(fn(self._h, t.data_ptr(), rows, cols, rs, cs, int(seed), int(row0),
+                   int(global_cols if global_cols is not None else cols)))
+        return t
+
+    def time_sketch(self, a, x, reps=10):
+        """Average duration (ms) of the sketch GEMM Y = A @ X measured with hipEvents on the library's
+        stream; returns (ms, Y)."""
+        import torch
+        m, n = a.shape
+        rs, cs = a.stride()
+        l = x.shape[1]
+        xc = x.t().contiguous()
+        y = torch.empty((l, m), dtype=a.dtype, device=a.device)
+        ms = C.c_double()
+        suf = "f32" if a.dtype == torch.float32 else "f64"
+        torch.cuda.current_stream(a.device).synchronize()
+        fn = getattr(self._lib, "corrla_time_sketch_dev_" + suf)
+        L.check(fn(self._h, a.data_ptr(), m, n, rs, cs, xc.data_ptr(), n, l, y.data_ptr(), m, int(reps), C.byref(ms)))
+        return ms.value, y.t()
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_context():
+    global _default
+    with _default_lock:
+        if _default is None:
+            _default = Context(0)
+        return _default
+
+
+def rsvd(a_mat, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, ctx=None):
+    """corrla_rs.rsvd(a_mat, n_rank, n_iters, n_oversamples) -> (U (m,k), S (k,1), Vt (k,n)).
+    src/lib_math_utils_py.rs:21-36."""
+    return (ctx or default_context()).rsvd(a_mat, n_rank, n_iters, n_oversamples, seed=seed, omega=omega)
+
+
+def random_svd(a_mat, omega_rank, n_iter, n_oversamples, *, seed=None, omega=None, ctx=None):
+    """random_svd(a_mat, omega_rank, n_iter, n_oversamples), random_svd.rs:63-66."""
+    return rsvd(a_mat, omega_rank, n_iter, n_oversamples, seed=seed, omega=omega, ctx=ctx)
+
+
+def power_iter(a_mat, omega_rank, n_iter, *, seed=None, omega=None, ctx=None):
+    """power_iter(a_mat, omega_rank, n_iter) -> Q (m, omega_rank), random_svd.rs:15-18.  `omega_rank` is
+    the already-oversampled sketch width."""
+    return (ctx or default_context()).power_iter(a_mat, omega_rank, n_iter, seed=seed, omega=omega)
+
+
+def algorithmic_flops(m, n, k, q, p):
+    """(4q+4) m n l + 2 m l^2 + (1 + max(0, q-3)) (4 m l^2 - 4/3 l^3), unpadded l."""
+    if m < n:
+        m, n = n, m
+    l = min(k + p, n)
+    return (4 * q + 4) * m * n * l + 2.0 * m * l * l + (1 + max(0, q - 3)) * (4.0 * m * l * l - 4.0 / 3.0 * l ** 3)

@@ -1,0 +1,211 @@
+// C-ABI glue shared by the product library (HIP backend) and the test-only emulation library:
+// argument validation, fat/tall + stride classification, staging of A, output orientation
+// (random_svd.rs:69-74, 96-109).  Templated on the backend; contains no m-/n-sized arithmetic.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/corrla_rsvd.h"
+#include "driver.hpp"
+
+namespace corrla {
+
+inline std::string& last_error_slot() {
+  static thread_local std::string msg;
+  return msg;
+}
+
+template <class F>
+inline corrla_status guarded(F&& f) {
+  try {
+    f();
+    return CORRLA_OK;
+  } catch (const Error& e) {
+    last_error_slot() = e.what();
+    return (corrla_status)e.code;
+  } catch (const std::bad_alloc&) {
+    last_error_slot() = "host allocation failed";
+    return CORRLA_ENOMEM;
+  } catch (const std::exception& e) {
+    last_error_slot() = e.what();
+    return CORRLA_EINVAL;
+  }
+}
+
+inline RunOpts parse_opts(const corrla_opts* o, bool dev_ptrs) {
+  RunOpts r;
+  if (!o) return r;
+  if (o->struct_size != sizeof(corrla_opts)) throw Error(ST_EINVAL, "corrla_opts.struct_size mismatch");
+  r.seed = o->seed ? o->seed : r.seed;
+  r.omega = o->omega;
+  r.omega_ld = o->omega_ld;
+  r.omega_on_device = (o->flags & CORRLA_OMEGA_ON_DEVICE) != 0;
+  if (r.omega_on_device && !dev_ptrs) throw Error(ST_EINVAL, "CORRLA_OMEGA_ON_DEVICE is only valid for *_dev entry points");
+  return r;
+}
+
+// Bring the strided input into one of the two layouts the kernels take and describe it as the
+// TALL matrix.  Host pointers are always staged (H2D) into a padded row-major device buffer;
+// device pointers are used in place when 16-byte vector loads are legal, else repacked.
+template <class Dev, class T>
+inline TallA<T> stage_input(Dev& dev, bool host_ptrs, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,
+                            bool force_tall) {
+  validate_matrix(a, m, n, rs, cs);
+  Layout L = classify(m, n, rs, cs);
+  if (force_tall && L.fat) {
+    // sharded / power_iter: never transpose (random_svd.rs:15-59 takes the matrix as given)
+    L = classify(m, n, rs, cs);
+    L.fat = false;
+    L.mt = m;
+    L.nt = n;
+    if ((cs == 1 || n == 1) && (rs >= n || m == 1)) {
+      L.row_major = true;
+      L.needs_pack = false;
+      L.ld = m == 1 ? n : rs;
+    } else if ((rs == 1 || m == 1) && (cs >= m || n == 1)) {
+      L.row_major = false;
+      L.needs_pack = false;
+      L.ld = n == 1 ? m : cs;
+    } else {
+      L.row_major = true;
+      L.needs_pack = true;
+      L.ld = n;
+    }
+  }
+  constexpr int64_t VEC = 16 / (int64_t)sizeof(T);
+  TallA<T> ta;
+  ta.mt = L.mt;
+  ta.nt = L.nt;
+  ta.row_major = L.row_major;
+  const int64_t mem_rows = L.row_major ? L.mt : L.nt;
+  const int64_t mem_cols = L.row_major ? L.nt : L.mt;
+  // strides of the memory-row-major view in the ORIGINAL array
+  int64_t vrs, vcs;
+  {
+    const int64_t trs = L.fat ? cs : rs, tcs = L.fat ? rs : cs;  // tall view strides
+    vrs = L.row_major ? trs : tcs;
+    vcs = L.row_major ? tcs : trs;
+  }
+  const bool aligned = !L.needs_pack && (((uintptr_t)a) % 16 == 0) && (L.ld % VEC == 0) && (mem_cols % VEC == 0);
+  if (!host_ptrs && aligned) {
+    ta.mem.p = a;
+    ta.mem.rows = mem_rows;
+    ta.mem.cols = mem_cols;
+    ta.mem.ld = L.ld;
+    ta.mem.cols_readable = mem_cols;
+    return ta;
+  }
+  const int64_t ldp = round_up(mem_cols, kLdPad);
+  T* buf = (T*)dev.alloc_bytes((size_t)mem_rows * (size_t)ldp * sizeof(T));
+  dev.memset_zero(buf, (size_t)mem_rows * (size_t)ldp * sizeof(T));
+  if (host_ptrs) {
+    if (L.needs_pack || vcs != 1) {
+      std::vector<T> packed((size_t)mem_rows * (size_t)mem_cols);
+      for (int64_t r = 0; r < mem_rows; ++r)
+        for (int64_t c = 0; c < mem_cols; ++c) packed[(size_t)r * mem_cols + c] = a[r * vrs + c * vcs];
+      dev.h2d_2d(buf, ldp, packed.data(), mem_cols, mem_cols, mem_rows);
+    } else {
+      dev.h2d_2d(buf, ldp, a, mem_rows == 1 ? mem_cols : vrs, mem_cols, mem_rows);
+    }
+  } else {
+    dev.pack_strided(a, mem_rows, mem_cols, vrs, vcs, buf, ldp);
+  }
+  ta.mem.p = buf;
+  ta.mem.rows = mem_rows;
+  ta.mem.cols = mem_cols;
+  ta.mem.ld = ldp;
+  ta.mem.cols_readable = ldp;
+  return ta;
+}
+
+template <class Dev, class T>
+inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,
+                       int64_t rank, int64_t n_iter, int64_t n_oversamples, const corrla_opts* opts, T* u, int64_t ldu,
+                       T* s, T* vt, int64_t ldvt, Timings* tm_out, bool profile) {
+  if (!u || !s || !vt) throw Error(ST_EINVAL, "output pointer is NULL");
+  validate_matrix(a, m, n, rs, cs);
+  if (sharded) {
+    if (rank < 1 || rank > n) throw Error(ST_EINVAL, "rank must be in [1, n] for the row-sharded path");
+    if (n_iter < 0 || n_oversamples < 0) throw Error(ST_EINVAL, "n_iter and n_oversamples must be >= 0");
+    if (dev.nranks() < 1) throw Error(ST_ECOMM, "communicator not initialised");
+  } else {
+    validate_rank(m, n, rank, n_iter, n_oversamples);
+  }
+  if (ldu < m) throw Error(ST_EINVAL, "ldu < m");
+  if (ldvt < rank) throw Error(ST_EINVAL, "ldvt < rank");
+  RunOpts ro = parse_opts(opts, !host_ptrs);
+  ro.sharded = sharded;
+  dev.begin_call();
+  TallA<T> ta = stage_input<Dev, T>(dev, host_ptrs, a, m, n, rs, cs, sharded);
+  const bool fat = !sharded && m < n;
+  const int64_t k = rank;
+  const int64_t l = std::min<int64_t>(rank + n_oversamples, ta.nt);  // random_svd.rs:77
+  if (ro.omega && ro.omega_ld < ta.nt) throw Error(ST_EINVAL, "omega_ld < min(m, n)");
+  RsvdDriver<Dev, T> drv(dev, profile);
+  Skinny<T> ut = dev.template alloc_skinny<T>(ta.mt, k);
+  Skinny<T> vtall = dev.template alloc_skinny<T>(ta.nt, k);
+  std::vector<double> sv;
+  drv.random_svd_tall(ta, k, l, n_iter, ro, ut, sv, vtall);
+  // random_svd.rs:96-109: tall -> (U, S, V^T); fat -> (V, S, U^T) of the transposed problem
+  if (!fat) {
+    dev.copy_out(ut, k, u, ldu, /*transpose=*/false, host_ptrs);
+    dev.copy_out(vtall, k, vt, ldvt, /*transpose=*/true, host_ptrs);
+  } else {
+    dev.copy_out(vtall, k, u, ldu, false, host_ptrs);
+    dev.copy_out(ut, k, vt, ldvt, true, host_ptrs);
+  }
+  std::vector<T> st(k);
+  for (int64_t i = 0; i < k; ++i) st[i] = (T)sv[i];
+  dev.store_values(st.data(), k, s, host_ptrs);
+  dev.end_call();
+  if (tm_out) *tm_out = drv.tm;
+}
+
+template <class Dev, class T>
+inline void power_iter_entry(Dev& dev, bool host_ptrs, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,
+                             int64_t width, int64_t n_iter, const corrla_opts* opts, T* q, int64_t ldq) {
+  if (!q) throw Error(ST_EINVAL, "q is NULL");
+  validate_matrix(a, m, n, rs, cs);
+  if (width < 1 || width > n) throw Error(ST_EINVAL, "width must be in [1, n]");
+  if (n_iter < 0) throw Error(ST_EINVAL, "n_iter must be >= 0");
+  if (ldq < m) throw Error(ST_EINVAL, "ldq < m");
+  RunOpts ro = parse_opts(opts, !host_ptrs);
+  if (ro.omega && ro.omega_ld < n) throw Error(ST_EINVAL, "omega_ld < n");
+  dev.begin_call();
+  TallA<T> ta = stage_input<Dev, T>(dev, host_ptrs, a, m, n, rs, cs, /*force_tall=*/true);
+  RsvdDriver<Dev, T> drv(dev, false);
+  Skinny<T> y = dev.template alloc_skinny<T>(ta.mt, width);
+  Skinny<T> y2 = dev.template alloc_skinny<T>(ta.mt, width);
+  drv.power_iter(ta, width, n_iter, ro, y, y2);
+  dev.copy_out(y, width, q, ldq, false, host_ptrs);
+  dev.end_call();
+}
+
+// res = beta * op(A) * X   (mat_utils.rs:20-33 for the two hot-path shapes)
+template <class Dev, class T>
+inline void matmul_entry(Dev& dev, int trans, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, const T* x,
+                         int64_t ldx, int64_t l, T beta, T* res, int64_t ldres) {
+  if (!x || !res) throw Error(ST_EINVAL, "x or res is NULL");
+  validate_matrix(a, m, n, rs, cs);
+  if (l < 1) throw Error(ST_EINVAL, "l must be >= 1");
+  const int64_t xin = trans ? m : n, xout = trans ? n : m;
+  if (ldx < xin || ldres < xout) throw Error(ST_EINVAL, "leading dimension too small");
+  dev.begin_call();
+  TallA<T> ta = stage_input<Dev, T>(dev, false, a, m, n, rs, cs, true);
+  RsvdDriver<Dev, T> drv(dev, false);
+  Skinny<T> xs = dev.template alloc_skinny<T>(xin, l);
+  dev.copy_in_skinny(x, ldx, xs);
+  Skinny<T> out = dev.template alloc_skinny<T>(xout, l);
+  T* beta_dev = dev.template alloc_scalar<T>(1);
+  dev.store_values(&beta, (int64_t)1, beta_dev, /*dst_is_host=*/false);
+  if (trans)
+    drv.at_times(ta, xs, out, beta_dev, false);
+  else
+    drv.a_times(ta, xs, out, beta_dev);
+  dev.copy_out(out, l, res, ldres, false, false);
+  dev.end_call();
+}
+
+}  // namespace corrla

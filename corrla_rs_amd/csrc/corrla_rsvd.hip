@@ -1,0 +1,191 @@
+// libcorrla_rsvd.so -- C ABI (include/corrla_rsvd.h) over the HIP backend.  This translation unit
+// is the product: it contains no CPU compute path; without a gfx950 device every compute entry
+// point returns CORRLA_ENODEV / CORRLA_EHIP.
+#include <mutex>
+
+#include "capi_impl.hpp"
+#include "hip_backend.hpp"
+
+using namespace corrla;
+
+struct corrla_ctx {
+  HipDev dev;
+  Timings last;
+  std::mutex mu;
+  bool profile;
+  explicit corrla_ctx(int ordinal) : dev(ordinal), profile(env_int("CORRLA_PROFILE_PHASES", 0) != 0) {}
+};
+
+namespace {
+inline corrla_ctx* need(corrla_ctx* c) {
+  if (!c) throw Error(ST_EINVAL, "ctx is NULL");
+  return c;
+}
+
+template <class T>
+corrla_status rsvd_c(corrla_ctx* ctx, bool host, bool sharded, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,
+                     int64_t rank, int64_t n_iter, int64_t p, const corrla_opts* o, T* u, int64_t ldu, T* s, T* vt,
+                     int64_t ldvt) {
+  return guarded([&] {
+    corrla_ctx* c = need(ctx);
+    std::lock_guard<std::mutex> lk(c->mu);
+    rsvd_entry<HipDev, T>(c->dev, host, sharded, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt, &c->last,
+                          c->profile);
+  });
+}
+template <class T>
+corrla_status power_c(corrla_ctx* ctx, bool host, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t width,
+                      int64_t n_iter, const corrla_opts* o, T* q, int64_t ldq) {
+  return guarded([&] {
+    corrla_ctx* c = need(ctx);
+    std::lock_guard<std::mutex> lk(c->mu);
+    power_iter_entry<HipDev, T>(c->dev, host, a, m, n, rs, cs, width, n_iter, o, q, ldq);
+  });
+}
+template <class T>
+corrla_status matmul_c(corrla_ctx* ctx, int trans, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, const T* x,
+                       int64_t ldx, int64_t l, T beta, T* res, int64_t ldres) {
+  return guarded([&] {
+    corrla_ctx* c = need(ctx);
+    std::lock_guard<std::mutex> lk(c->mu);
+    matmul_entry<HipDev, T>(c->dev, trans, a, m, n, rs, cs, x, ldx, l, beta, res, ldres);
+  });
+}
+template <class T>
+corrla_status fill_c(corrla_ctx* ctx, T* p, int64_t rows, int64_t cols, int64_t rs, int64_t cs, uint64_t seed,
+                     int64_t row0, int64_t global_cols) {
+  return guarded([&] {
+    corrla_ctx* c = need(ctx);
+    if (!p) throw Error(ST_EINVAL, "p is NULL");
+    if (rows < 0 || cols < 0 || rs < 0 || cs < 0 || global_cols < cols) throw Error(ST_EINVAL, "bad fill_normal shape");
+    std::lock_guard<std::mutex> lk(c->mu);
+    CORRLA_HIP(hipSetDevice(c->dev.device));
+    c->dev.fill_normal(p, rows, cols, rs, cs, seed, row0, global_cols);
+    c->dev.sync();
+  });
+}
+template <class T>
+corrla_status time_sketch_c(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, const T* x,
+                            int64_t ldx, int64_t l, T* y, int64_t ldy, int reps, double* avg_ms) {
+  return guarded([&] {
+    corrla_ctx* c = need(ctx);
+    if (!x || !y || !avg_ms) throw Error(ST_EINVAL, "NULL argument");
+    if (reps < 1 || l < 1 || ldx < n || ldy < m) throw Error(ST_EINVAL, "bad time_sketch arguments");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HipDev& dev = c->dev;
+    dev.begin_call();
+    TallA<T> ta = stage_input<HipDev, T>(dev, false, a, m, n, rs, cs, true);
+    RsvdDriver<HipDev, T> drv(dev, false);
+    Skinny<T> xs = dev.alloc_skinny<T>(n, l);
+    dev.copy_in_skinny(x, ldx, xs);
+    Skinny<T> out = dev.alloc_skinny<T>(m, l);
+    *avg_ms = dev.time_on_stream(reps, [&] { drv.a_times(ta, xs, out, nullptr); });
+    dev.copy_out(out, l, y, ldy, false, false);
+    dev.end_call();
+  });
+}
+}  // namespace
+
+extern "C" {
+
+const char* corrla_version(void) { return "corrla_rsvd 0.1.0 gfx950"; }
+const char* corrla_last_error(void) { return last_error_slot().c_str(); }
+int corrla_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+corrla_status corrla_ctx_create(int device_ordinal, corrla_ctx** out) {
+  return guarded([&] {
+    if (!out) throw Error(ST_EINVAL, "out is NULL");
+    *out = nullptr;
+    *out = new corrla_ctx(device_ordinal);
+  });
+}
+void corrla_ctx_destroy(corrla_ctx* ctx) { delete ctx; }
+corrla_status corrla_ctx_synchronize(corrla_ctx* ctx) {
+  return guarded([&] { need(ctx)->dev.sync(); });
+}
+corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out) {
+  return guarded([&] {
+    corrla_ctx* c = need(ctx);
+    if (!out) throw Error(ST_EINVAL, "out is NULL");
+    const Timings& t = c->last;
+    out->total_ms = t.total_ms;
+    out->sketch_ms = t.sketch_ms;
+    out->power_ms = t.power_ms;
+    out->qr_ms = t.qr_ms;
+    out->project_ms = t.project_ms;
+    out->small_svd_ms = t.small_svd_ms;
+    out->finalize_ms = t.finalize_ms;
+    out->qr_passes = t.qr_passes;
+    out->reserved = 0;
+  });
+}
+
+#define CORRLA_DEFINE(SUF, T)                                                                                          \
+  corrla_status corrla_rsvd_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,           \
+                                  int64_t rank, int64_t n_iter, int64_t p, const corrla_opts* o, T* u, int64_t ldu,    \
+                                  T* s, T* vt, int64_t ldvt) {                                                         \
+    return rsvd_c<T>(ctx, true, false, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt);                      \
+  }                                                                                                                    \
+  corrla_status corrla_rsvd_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,       \
+                                      int64_t rank, int64_t n_iter, int64_t p, const corrla_opts* o, T* u,             \
+                                      int64_t ldu, T* s, T* vt, int64_t ldvt) {                                        \
+    return rsvd_c<T>(ctx, false, false, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt);                     \
+  }                                                                                                                    \
+  corrla_status corrla_rsvd_sharded_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs,           \
+                                              int64_t cs, int64_t rank, int64_t n_iter, int64_t p,                     \
+                                              const corrla_opts* o, T* u, int64_t ldu, T* s, T* vt, int64_t ldvt) {    \
+    return rsvd_c<T>(ctx, false, true, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt);                      \
+  }                                                                                                                    \
+  corrla_status corrla_power_iter_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,     \
+                                        int64_t width, int64_t n_iter, const corrla_opts* o, T* q, int64_t ldq) {      \
+    return power_c<T>(ctx, true, a, m, n, rs, cs, width, n_iter, o, q, ldq);                                           \
+  }                                                                                                                    \
+  corrla_status corrla_power_iter_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs,             \
+                                            int64_t cs, int64_t width, int64_t n_iter, const corrla_opts* o, T* q,     \
+                                            int64_t ldq) {                                                             \
+    return power_c<T>(ctx, false, a, m, n, rs, cs, width, n_iter, o, q, ldq);                                          \
+  }                                                                                                                    \
+  corrla_status corrla_matmul_dev_##SUF(corrla_ctx* ctx, int trans, const T* a, int64_t m, int64_t n, int64_t rs,      \
+                                        int64_t cs, const T* x, int64_t ldx, int64_t l, T beta, T* res,                \
+                                        int64_t ldres) {                                                               \
+    return matmul_c<T>(ctx, trans, a, m, n, rs, cs, x, ldx, l, beta, res, ldres);                                      \
+  }                                                                                                                    \
+  corrla_status corrla_fill_normal_dev_##SUF(corrla_ctx* ctx, T* p, int64_t rows, int64_t cols, int64_t rs,            \
+                                             int64_t cs, uint64_t seed, int64_t row0, int64_t global_cols) {           \
+    return fill_c<T>(ctx, p, rows, cols, rs, cs, seed, row0, global_cols);                                             \
+  }                                                                                                                    \
+  corrla_status corrla_time_sketch_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs,            \
+                                             int64_t cs, const T* x, int64_t ldx, int64_t l, T* y, int64_t ldy,        \
+                                             int reps, double* avg_ms) {                                               \
+    return time_sketch_c<T>(ctx, a, m, n, rs, cs, x, ldx, l, y, ldy, reps, avg_ms);                                    \
+  }
+
+CORRLA_DEFINE(f32, float)
+CORRLA_DEFINE(f64, double)
+
+corrla_status corrla_comm_unique_id(void* out128) {
+  return guarded([&] {
+    if (!out128) throw Error(ST_EINVAL, "out128 is NULL");
+    ncclUniqueId id;
+    CORRLA_NCCL(ncclGetUniqueId(&id));
+    std::memset(out128, 0, CORRLA_UNIQUE_ID_BYTES);
+    std::memcpy(out128, &id, sizeof(id));
+  });
+}
+corrla_status corrla_ctx_comm_init(corrla_ctx* ctx, const void* unique_id128, int rank, int nranks) {
+  return guarded([&] {
+    corrla_ctx* c = need(ctx);
+    if (!unique_id128 || nranks < 1 || rank < 0 || rank >= nranks) throw Error(ST_EINVAL, "bad communicator arguments");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->dev.comm_init(unique_id128, rank, nranks);
+  });
+}
+
+}  // extern "C"

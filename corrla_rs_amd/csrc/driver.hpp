@@ -1,0 +1,370 @@
+// Algorithm driver for the RSVD hot path: the schedule of random_svd.rs:15-110 expressed over
+// a device backend `Dev` that supplies the m-/n-sized operations (tall GEMMs, norms, fills).
+// The product instantiates it with the HIP backend (hip_backend.hpp); tests/emu instantiates it
+// with a host emulation backend to exercise THIS file's logic (shapes, fat/tall handling,
+// orthonormalisation passes, sharded exchange points) without a GPU.  No arithmetic on m- or
+// n-sized data happens in this file.
+#pragma once
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "small_linalg.hpp"
+
+namespace corrla {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+enum { ST_OK = 0, ST_EINVAL = 1, ST_ENOMEM = 2, ST_EHIP = 3, ST_ECOMM = 4, ST_ENUMERIC = 5, ST_ENODEV = 6 };
+
+inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// Skinny matrices (Omega, Y, Z, Q, B^T, small l x l operands) are column-major device
+// buffers with a leading dimension padded to 64 elements and a column count padded to the
+// kernel's column blocking; ALL padding is kept zero so the GEMM kernels never bounds-check them.
+constexpr int kMaxColTiles = 9;  // 16-column MFMA tiles per workgroup column block (144 columns)
+constexpr int kLdPad = 64;
+
+struct ColBlocking {
+  int tiles, nblk, nt;
+  int64_t cols_alloc;
+};
+inline ColBlocking col_blocking(int64_t cols) {
+  ColBlocking b;
+  b.tiles = (int)std::max<int64_t>(1, (cols + 15) / 16);
+  b.nblk = (b.tiles + kMaxColTiles - 1) / kMaxColTiles;
+  b.nt = (b.tiles + b.nblk - 1) / b.nblk;
+  b.cols_alloc = (int64_t)b.nblk * b.nt * 16;
+  return b;
+}
+
+template <class T>
+struct Skinny {
+  T* p = nullptr;
+  int64_t rows = 0, cols = 0, ld = 0, cols_alloc = 0;
+  Skinny view_cols(int64_t c) const {
+    Skinny s = *this;
+    s.cols = c;
+    return s;
+  }
+};
+
+// Row-major view of memory: element (r, c) at p[r * ld + c].  cols_readable >= cols is how far
+// each row may be read (vector loads); entries in [cols, cols_readable) are zero.
+template <class T>
+struct Big {
+  const T* p = nullptr;
+  int64_t rows = 0, cols = 0, ld = 0, cols_readable = 0;
+};
+
+// A skinny column-major matrix reinterpreted as the row-major matrix of its transpose.
+template <class T>
+inline Big<T> as_rowmajor_transposed(const Skinny<T>& y, int64_t ncols) {
+  Big<T> b;
+  b.p = y.p;
+  b.rows = ncols;
+  b.cols = y.rows;
+  b.ld = y.ld;
+  b.cols_readable = y.ld;
+  return b;
+}
+
+// The TALL matrix A (mt x nt, mt >= nt unless the caller insists otherwise) as it sits in
+// memory: either row-major (mem = A) or column-major (mem = A^T as a row-major nt x mt).
+template <class T>
+struct TallA {
+  Big<T> mem;
+  bool row_major = true;
+  int64_t mt = 0, nt = 0;  // local rows (sharded) x columns
+};
+
+struct RunOpts {
+  uint64_t seed = 0x5eedull;
+  const void* omega = nullptr;  // column-major nt x l, dtype T
+  int64_t omega_ld = 0;
+  bool omega_on_device = false;
+  bool sharded = false;  // rows of A are sharded over the communicator
+};
+
+struct Timings {
+  double total_ms = 0, sketch_ms = 0, power_ms = 0, qr_ms = 0, project_ms = 0, small_svd_ms = 0, finalize_ms = 0;
+  int qr_passes = 0;
+};
+
+struct PhaseTimer {
+  using clk = std::chrono::steady_clock;
+  clk::time_point t0;
+  PhaseTimer() : t0(clk::now()) {}
+  double lap() {
+    auto t1 = clk::now();
+    double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    t0 = t1;
+    return ms;
+  }
+};
+
+template <class Dev, class T>
+struct RsvdDriver {
+  Dev& dev;
+  Timings tm;
+  bool profile_phases;  // synchronise at phase boundaries to attribute time
+  static constexpr const T* kNone = nullptr;
+
+  explicit RsvdDriver(Dev& d, bool profile = false) : dev(d), profile_phases(profile) {}
+
+  // ---- op(A) * skinny ---------------------------------------------------------------
+  // Y (mt x L) = scale * A * X (nt x L)                         random_svd.rs:31,47-51
+  void a_times(const TallA<T>& a, const Skinny<T>& x, Skinny<T>& y, const T* scale_dev) {
+    if (a.row_major)
+      dev.gemm_nn(a.mem, x, y, scale_dev);
+    else
+      dev.gemm_tn(a.mem, x, y, scale_dev);
+  }
+  // Z (nt x L) = scale * A^T * Y (mt x L); all-reduced when rows are sharded   random_svd.rs:42-46,80
+  void at_times(const TallA<T>& a, const Skinny<T>& y, Skinny<T>& z, const T* scale_dev, bool sharded) {
+    if (a.row_major)
+      dev.gemm_tn(a.mem, y, z, scale_dev);
+    else
+      dev.gemm_nn(a.mem, y, z, scale_dev);
+    if (sharded) dev.allreduce(z.p, (size_t)z.ld * (size_t)z.cols_alloc);
+  }
+
+  // ---- thin-Q orthonormalisation (replaces y.qr().compute_thin_q(), random_svd.rs:38,57) ----
+  // Iterated Cholesky-QR on the device-computed Gram matrix: G = Y^T Y (tall GEMM + optional
+  // all-reduce), host Cholesky of the l x l G in f64, Y <- Y * R^-1 (tall GEMM).  A pass whose
+  // Gram was already within 0.25 of I leaves Y orthonormal to O(eps), so well-conditioned
+  // sketches take two passes.  Numerically singular Grams get a diagonal shift (shifted
+  // CholeskyQR, Fukaya et al. 2020); if three shifted passes do not recover full rank the
+  // deficient directions are exact-null and are dropped through an eigen-decomposition of G:
+  // the result then has r < l orthonormal columns followed by zero columns, which is how the
+  // rest of the pipeline represents "arbitrary completion" directions of a rank-deficient QR
+  // (their singular values are 0 either way; random_svd.rs:153-196 exercises this).
+  // Returns the number of non-zero (orthonormal) columns.
+  int64_t orthonormalize(Skinny<T>& y, Skinny<T>& tmp, bool sharded) {
+    const int64_t l = y.cols;
+    int64_t r = l;
+    const double eps = (double)std::numeric_limits<T>::epsilon();
+    std::vector<double> g((size_t)l * l), mm((size_t)l * l), uu, ss, vv;
+    Skinny<T> gd = dev.template alloc_skinny<T>(l, l);
+    Skinny<T> md = dev.template alloc_skinny<T>(l, l);
+    int fails = 0;
+    for (int pass = 0; pass < 12; ++pass) {
+      if (r == 0) break;
+      // G (r x r) = Y[:, :r]^T Y[:, :r]
+      Skinny<T> yv = y.view_cols(r);
+      Skinny<T> gv = gd.view_cols(r);
+      gv.rows = r;
+      dev.gemm_nn(as_rowmajor_transposed(y, r), yv, gv, kNone);
+      if (sharded) dev.allreduce(gd.p, (size_t)gd.ld * (size_t)gd.cols_alloc);
+      dev.download_skinny(gv, r, r, g.data());
+      ++tm.qr_passes;
+      double gmax = 0.0, dev_i = 0.0;
+      for (int64_t j = 0; j < r; ++j)
+        for (int64_t i = 0; i < r; ++i) {
+          const double x = g[(size_t)j * r + i];
+          if (!std::isfinite(x)) throw Error(ST_ENUMERIC, "non-finite Gram matrix in orthonormalisation");
+          dev_i = std::max(dev_i, std::fabs(x - (i == j ? 1.0 : 0.0)));
+          if (i == j) gmax = std::max(gmax, x);
+        }
+      if (gmax == 0.0) {
+        r = 0;
+        break;
+      }
+      if (dev_i <= 16.0 * eps) break;  // already orthonormal at working precision
+      const bool near_i = dev_i <= 0.25;
+      int64_t r_new = r;
+      bool clean = false;
+      if (fails >= 3) {
+        // exact-null directions: drop them.  G = V diag(lam) V^T (Jacobi on the symmetric G).
+        uu.resize((size_t)r * r);
+        vv.resize((size_t)r * r);
+        ss.resize(r);
+        if (small::jacobi_svd((int)r, g.data(), (int)r, uu.data(), ss.data(), vv.data(), 1e-15) < 0)
+          throw Error(ST_ENUMERIC, "non-finite Gram matrix in orthonormalisation");
+        r_new = 0;
+        while (r_new < r && ss[r_new] > 1e-2 * ss[0]) ++r_new;
+        std::fill(mm.begin(), mm.end(), 0.0);
+        for (int64_t j = 0; j < r_new; ++j) {
+          const double sc = 1.0 / std::sqrt(ss[j]);
+          for (int64_t i = 0; i < r; ++i) mm[(size_t)j * r + i] = vv[(size_t)j * r + i] * sc;
+        }
+        fails = 0;
+      } else {
+        std::vector<double> rr(g.begin(), g.begin() + (size_t)r * r);
+        double min_ratio = 0.0;
+        clean = small::chol_upper((int)r, rr.data(), (int)r, 4.0 * eps, &min_ratio);
+        if (!clean) {
+          ++fails;
+          double shift = 16.0 * eps * gmax;
+          bool ok = false;
+          for (int tries = 0; tries < 8 && !ok; ++tries, shift *= 10.0) {
+            rr.assign(g.begin(), g.begin() + (size_t)r * r);
+            for (int64_t i = 0; i < r; ++i) rr[(size_t)i * r + i] += shift;
+            ok = small::chol_upper((int)r, rr.data(), (int)r, 0.0, &min_ratio);
+          }
+          if (!ok) throw Error(ST_ENUMERIC, "Gram matrix not positive definite even after shifting");
+        } else {
+          fails = 0;
+        }
+        small::triu_inverse((int)r, rr.data(), (int)r);
+        std::copy(rr.begin(), rr.end(), mm.begin());
+      }
+      // Y[:, :r_new] <- Y[:, :r] * M (r x r_new); columns >= r_new become zero.
+      Skinny<T> mv = md.view_cols(r_new);
+      mv.rows = r;
+      dev.upload_skinny(mm.data(), r, r_new, r, md);
+      Skinny<T> out = tmp.view_cols(r_new);
+      dev.gemm_tn(as_rowmajor_transposed(y, r), mv, out, kNone);
+      if (r_new < l) dev.zero_cols(tmp, r_new, l);
+      std::swap(y.p, tmp.p);
+      r = r_new;
+      if (clean && near_i) break;
+    }
+    return r;
+  }
+
+  // ---- power_iter, random_svd.rs:15-59 -------------------------------------------------
+  // Leaves the orthonormal basis in `y` (mt x l) and returns its numerical rank.
+  int64_t power_iter(const TallA<T>& a, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& y, Skinny<T>& y2) {
+    PhaseTimer pt;
+    Skinny<T> om = dev.template alloc_skinny<T>(a.nt, l);
+    if (o.omega) {
+      if (o.omega_on_device)
+        dev.copy_in_skinny((const T*)o.omega, o.omega_ld, om);
+      else
+        dev.upload_skinny_native((const T*)o.omega, o.omega_ld, om);
+    } else {
+      // random_mat_normal(a_ncols, omega_rank), random_svd.rs:24 / mat_utils.rs:161-175
+      dev.fill_normal(om.p, a.nt, l, 1, om.ld, o.seed, 0, l);
+    }
+    Skinny<T> z = dev.template alloc_skinny<T>(a.nt, l);
+    double* ss_dev = dev.alloc_f64(1);
+    T* inv_dev = dev.template alloc_scalar<T>(1);
+    a_times(a, om, y, kNone);  // :31
+    phase(tm.sketch_ms, pt);
+    const T* scale = nullptr;
+    for (int64_t i = 0; i < n_iter; ++i) {  // :35
+      if (i > 2) {                          // :37-39
+        if (scale) dev.scale_inplace(y, scale);
+        phase(tm.power_ms, pt);
+        orthonormalize(y, y2, o.sharded);
+        phase(tm.qr_ms, pt);
+        scale = nullptr;
+      }
+      at_times(a, y, z, scale, o.sharded);  // :42-46 (the 1/||Y||_F of :53-55 is folded in here)
+      a_times(a, z, y, kNone);            // :47-51
+      dev.sumsq(y, ss_dev);                 // :54 norm_l2 (Frobenius)
+      if (o.sharded) dev.allreduce_f64(ss_dev, 1);
+      dev.rsqrt_scalar(ss_dev, inv_dev);
+      scale = inv_dev;
+    }
+    if (scale) dev.scale_inplace(y, scale);  // :53-55 for the last iteration
+    phase(tm.power_ms, pt);
+    int64_t r = orthonormalize(y, y2, o.sharded);  // :57
+    phase(tm.qr_ms, pt);
+    return r;
+  }
+
+  // ---- random_svd, random_svd.rs:63-110, on the already-tall view ------------------------
+  // u_tall: mt x k, v_tall: nt x k (both skinny, allocated by the caller), s: k values.
+  void random_svd_tall(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
+                       std::vector<double>& s, Skinny<T>& v_tall) {
+    PhaseTimer total;
+    Skinny<T> q = dev.template alloc_skinny<T>(a.mt, l);
+    Skinny<T> q2 = dev.template alloc_skinny<T>(a.mt, l);
+    power_iter(a, l, n_iter, o, q, q2);  // :76-77
+    PhaseTimer pt;
+    // B^T = A^T Q  (n x l)                                                           :80
+    Skinny<T> bt = dev.template alloc_skinny<T>(a.nt, l);
+    at_times(a, q, bt, kNone, o.sharded);
+    phase(tm.project_ms, pt);
+    // SVD of B (l x n), :89.  The reference takes faer's full SVD and slices; here:
+    // B^T = Qb C with Qb orthonormal (n x l) and C = Qb^T B^T (l x l); C = Uc S Vc^T on the host;
+    // => B = Vc S (Qb Uc)^T, i.e. U~ = Vc and V = Qb Uc.
+    Skinny<T> qb = dev.template alloc_skinny<T>(a.nt, l);
+    Skinny<T> qb2 = dev.template alloc_skinny<T>(a.nt, l);
+    dev.copy_skinny(bt, qb);
+    orthonormalize(qb, qb2, false);
+    phase(tm.qr_ms, pt);
+    Skinny<T> cd = dev.template alloc_skinny<T>(l, l);
+    dev.gemm_nn(as_rowmajor_transposed(qb, l), bt, cd, kNone);
+    std::vector<double> c((size_t)l * l), uc((size_t)l * l), vc((size_t)l * l), sv(l);
+    dev.download_skinny(cd, l, l, c.data());
+    const double eps = (double)std::numeric_limits<T>::epsilon();
+    if (small::jacobi_svd((int)l, c.data(), (int)l, uc.data(), sv.data(), vc.data(), std::max(1e-15, eps * 1e-3)) < 0)
+      throw Error(ST_ENUMERIC, "non-finite core matrix in small SVD");
+    s.assign(sv.begin(), sv.begin() + k);
+    phase(tm.small_svd_ms, pt);
+    // U = Q * U~[:, :k]                                                               :92, :96-109
+    Skinny<T> m1 = dev.template alloc_skinny<T>(l, k);
+    dev.upload_skinny(vc.data(), l, k, l, m1);
+    dev.gemm_tn(as_rowmajor_transposed(q, l), m1, u_tall, kNone);
+    // V = Qb * Uc[:, :k]
+    Skinny<T> m2 = dev.template alloc_skinny<T>(l, k);
+    dev.upload_skinny(uc.data(), l, k, l, m2);
+    dev.gemm_tn(as_rowmajor_transposed(qb, l), m2, v_tall, kNone);
+    phase(tm.finalize_ms, pt);
+    tm.total_ms += total.lap();
+  }
+
+  void phase(double& slot, PhaseTimer& pt) {
+    if (profile_phases) dev.sync();
+    slot += pt.lap();
+  }
+};
+
+// ---- argument handling shared by the C ABI of the product and of the test emulation --------
+struct Layout {
+  bool fat;        // m < n (strict, random_svd.rs:71): work on A^T
+  bool row_major;  // the TALL view is row-major in memory
+  bool needs_pack; // neither stride is 1, or vector alignment not met: repack first
+  int64_t mt, nt, ld;
+};
+
+inline void validate_matrix(const void* a, int64_t m, int64_t n, int64_t rs, int64_t cs) {
+  if (!a) throw Error(ST_EINVAL, "a is NULL");
+  if (m < 1 || n < 1) throw Error(ST_EINVAL, "matrix must have at least one row and one column");
+  if (rs < 0 || cs < 0) throw Error(ST_EINVAL, "negative strides are not supported");
+  if (m > 1 && rs == 0) throw Error(ST_EINVAL, "row_stride == 0 with more than one row");
+  if (n > 1 && cs == 0) throw Error(ST_EINVAL, "col_stride == 0 with more than one column");
+}
+
+// Classify a (m, n, rs, cs) strided matrix into the tall row-/column-major views the kernels take.
+inline Layout classify(int64_t m, int64_t n, int64_t rs, int64_t cs) {
+  Layout L;
+  L.fat = m < n;
+  L.mt = L.fat ? n : m;
+  L.nt = L.fat ? m : n;
+  // strides of the tall view
+  const int64_t trs = L.fat ? cs : rs, tcs = L.fat ? rs : cs;
+  L.needs_pack = false;
+  if ((tcs == 1 || L.nt == 1) && (trs >= L.nt || L.mt == 1)) {
+    L.row_major = true;
+    L.ld = L.mt == 1 ? L.nt : trs;
+  } else if ((trs == 1 || L.mt == 1) && (tcs >= L.mt || L.nt == 1)) {
+    L.row_major = false;
+    L.ld = L.nt == 1 ? L.mt : tcs;
+  } else {
+    L.row_major = true;
+    L.needs_pack = true;
+    L.ld = L.nt;
+  }
+  return L;
+}
+
+inline void validate_rank(int64_t m, int64_t n, int64_t rank, int64_t n_iter, int64_t n_oversamples) {
+  if (rank < 1) throw Error(ST_EINVAL, "rank must be >= 1");
+  if (n_iter < 0 || n_oversamples < 0) throw Error(ST_EINVAL, "n_iter and n_oversamples must be >= 0");
+  // random_svd.rs:98-107: slicing 0..omega_rank past l = min(rank+p, min(m,n)) panics in the reference
+  if (rank > std::min(m, n)) throw Error(ST_EINVAL, "rank exceeds min(m, n) (the reference panics here)");
+  if (rank + n_oversamples > (int64_t)1 << 20) throw Error(ST_EINVAL, "rank + n_oversamples too large");
+}
+
+}  // namespace corrla

@@ -1,0 +1,439 @@
+// HIP backend of the RSVD driver: one device, one stream, one cached workspace arena and
+// (optionally) one RCCL communicator per context.  Implements the `Dev` interface that
+// driver.hpp / capi_impl.hpp are written against.  Every operation is enqueued on the context's
+// stream; the only host synchronisations are the small l x l downloads the host factorizations need.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "driver.hpp"
+#include "hip_kernels.hpp"
+
+namespace corrla {
+
+#define CORRLA_HIP(call)                                                                                       \
+  do {                                                                                                         \
+    hipError_t e_ = (call);                                                                                    \
+    if (e_ != hipSuccess)                                                                                      \
+      throw Error(ST_EHIP, std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" +       \
+                               std::to_string(__LINE__) + ")");                                                \
+  } while (0)
+#define CORRLA_NCCL(call)                                                                                      \
+  do {                                                                                                         \
+    ncclResult_t r_ = (call);                                                                                  \
+    if (r_ != ncclSuccess) throw Error(ST_ECOMM, std::string(#call) + " failed: " + ncclGetErrorString(r_));   \
+  } while (0)
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : dflt;
+}
+
+template <class T>
+struct NcclType;
+template <>
+struct NcclType<float> {
+  static constexpr ncclDataType_t v = ncclFloat;
+};
+template <>
+struct NcclType<double> {
+  static constexpr ncclDataType_t v = ncclDouble;
+};
+
+class HipDev {
+ public:
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
+
+  explicit HipDev(int dev_ordinal) : device(dev_ordinal) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+      throw Error(ST_ENODEV, "no HIP device visible (libcorrla_rsvd has no CPU fallback)");
+    if (dev_ordinal < 0 || dev_ordinal >= count) throw Error(ST_EINVAL, "device ordinal out of range");
+    CORRLA_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CORRLA_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      throw Error(ST_ENODEV, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    num_cus = prop.multiProcessorCount;
+    CORRLA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    CORRLA_HIP(hipMalloc(&zero_page_, 256));
+    CORRLA_HIP(hipMemsetAsync(zero_page_, 0, 256, stream));
+    set_lds_attrs<float>();
+    set_lds_attrs<double>();
+    split_nn_override_ = env_int("CORRLA_SPLIT_NN", 0);
+    split_tn_override_ = env_int("CORRLA_SPLIT_TN", 0);
+  }
+  ~HipDev() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (comm) (void)ncclCommDestroy(comm);
+    for (auto& c : chunks_) (void)hipFree(c.p);
+    if (zero_page_) (void)hipFree(zero_page_);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  HipDev(const HipDev&) = delete;
+  HipDev& operator=(const HipDev&) = delete;
+
+  int nranks() const { return comm_size; }
+
+  void comm_init(const void* id128, int rank, int nranks_) {
+    CORRLA_HIP(hipSetDevice(device));
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) <= CORRLA_UNIQUE_ID_BYTES, "unique id size");
+    std::memcpy(&id, id128, sizeof(id));
+    if (comm) {
+      (void)ncclCommDestroy(comm);
+      comm = nullptr;
+    }
+    CORRLA_NCCL(ncclCommInitRank(&comm, nranks_, id, rank));
+    comm_rank = rank;
+    comm_size = nranks_;
+  }
+
+  // ---- memory ----------------------------------------------------------------------------
+  void begin_call() {
+    CORRLA_HIP(hipSetDevice(device));
+    for (auto& c : chunks_) c.used = 0;
+  }
+  void end_call() { sync(); }
+  void sync() { CORRLA_HIP(hipStreamSynchronize(stream)); }
+
+  void* alloc_bytes(size_t bytes) {
+    bytes = (bytes + 255) / 256 * 256;
+    if (bytes == 0) bytes = 256;
+    for (auto& c : chunks_)
+      if (c.size - c.used >= bytes) {
+        void* p = (char*)c.p + c.used;
+        c.used += bytes;
+        return p;
+      }
+    Chunk c;
+    c.size = std::max<size_t>(bytes, (size_t)64 << 20);
+    if (hipMalloc(&c.p, c.size) != hipSuccess) {
+      (void)hipGetLastError();
+      throw Error(ST_ENOMEM, "device allocation of " + std::to_string(c.size) + " bytes failed");
+    }
+    c.used = bytes;
+    chunks_.push_back(c);
+    return c.p;
+  }
+  void memset_zero(void* p, size_t bytes) { CORRLA_HIP(hipMemsetAsync(p, 0, bytes, stream)); }
+
+  template <class T>
+  Skinny<T> alloc_skinny(int64_t rows, int64_t cols) {
+    Skinny<T> s;
+    s.rows = rows;
+    s.cols = cols;
+    s.ld = round_up(std::max<int64_t>(rows, 1), kLdPad);
+    s.cols_alloc = col_blocking(cols).cols_alloc;
+    const size_t bytes = (size_t)s.ld * (size_t)s.cols_alloc * sizeof(T);
+    s.p = (T*)alloc_bytes(bytes);
+    memset_zero(s.p, bytes);
+    return s;
+  }
+  double* alloc_f64(int n) {
+    double* p = (double*)alloc_bytes(sizeof(double) * n);
+    memset_zero(p, sizeof(double) * n);
+    return p;
+  }
+  template <class T>
+  T* alloc_scalar(int n) {
+    T* p = (T*)alloc_bytes(sizeof(T) * n);
+    memset_zero(p, sizeof(T) * n);
+    return p;
+  }
+
+  void h2d_2d(void* dst, int64_t dpitch_e, const void* src, int64_t spitch_e, int64_t width_e, int64_t rows, size_t esz) {
+    CORRLA_HIP(hipMemcpy2DAsync(dst, (size_t)dpitch_e * esz, src, (size_t)spitch_e * esz, (size_t)width_e * esz,
+                                (size_t)rows, hipMemcpyHostToDevice, stream));
+    sync();
+  }
+  template <class T>
+  void h2d_2d(T* dst, int64_t dpitch_e, const T* src, int64_t spitch_e, int64_t width_e, int64_t rows) {
+    h2d_2d((void*)dst, dpitch_e, (const void*)src, spitch_e, width_e, rows, sizeof(T));
+  }
+
+  // ---- GEMMs -----------------------------------------------------------------------------
+  template <class T>
+  void gemm_nn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale_dev) {
+    if (x.rows != r.cols) throw Error(ST_EINVAL, "gemm_nn: inner dimensions differ");
+    launch_gemm<T>(false, r, x, out, scale_dev, r.rows, r.cols);
+  }
+  template <class T>
+  void gemm_tn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale_dev) {
+    if (x.rows != r.rows) throw Error(ST_EINVAL, "gemm_tn: inner dimensions differ");
+    launch_gemm<T>(true, r, x, out, scale_dev, r.cols, r.rows);
+  }
+
+  // ---- collectives (RCCL over xGMI, on the compute stream) ---------------------------------
+  template <class T>
+  void allreduce(T* p, size_t count) {
+    if (comm_size <= 1) return;
+    if (!comm) throw Error(ST_ECOMM, "communicator not initialised");
+    CORRLA_NCCL(ncclAllReduce(p, p, count, NcclType<T>::v, ncclSum, comm, stream));
+  }
+  void allreduce_f64(double* p, size_t count) { allreduce<double>(p, count); }
+
+  // ---- small transfers -------------------------------------------------------------------
+  // device skinny (rows x cols leading block) -> host f64 column-major (ld = rows); synchronises
+  template <class T>
+  void download_skinny(const Skinny<T>& s, int64_t rows, int64_t cols, double* host) {
+    std::vector<T> tmp((size_t)rows * cols);
+    CORRLA_HIP(hipMemcpy2DAsync(tmp.data(), (size_t)rows * sizeof(T), s.p, (size_t)s.ld * sizeof(T),
+                                (size_t)rows * sizeof(T), (size_t)cols, hipMemcpyDeviceToHost, stream));
+    sync();
+    for (size_t i = 0; i < tmp.size(); ++i) host[i] = (double)tmp[i];
+  }
+  // host f64 column-major (rows x cols, ld_host) -> device skinny; the whole allocation is
+  // rewritten so padding stays zero
+  template <class T>
+  void upload_skinny(const double* host, int64_t rows, int64_t cols, int64_t ld_host, Skinny<T>& dst) {
+    std::vector<T> tmp((size_t)dst.ld * dst.cols_alloc, (T)0);
+    for (int64_t j = 0; j < cols; ++j)
+      for (int64_t i = 0; i < rows; ++i) tmp[(size_t)j * dst.ld + i] = (T)host[(size_t)j * ld_host + i];
+    CORRLA_HIP(hipMemcpyAsync(dst.p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+    sync();
+  }
+  template <class T>
+  void upload_skinny_native(const T* host, int64_t ld_host, Skinny<T>& dst) {
+    h2d_2d(dst.p, dst.ld, host, ld_host, dst.rows, dst.cols);
+  }
+  template <class T>
+  void copy_in_skinny(const T* src_dev, int64_t ld_src, Skinny<T>& dst) {
+    CORRLA_HIP(hipMemcpy2DAsync(dst.p, (size_t)dst.ld * sizeof(T), src_dev, (size_t)ld_src * sizeof(T),
+                                (size_t)dst.rows * sizeof(T), (size_t)dst.cols, hipMemcpyDeviceToDevice, stream));
+  }
+  template <class T>
+  void copy_skinny(const Skinny<T>& src, Skinny<T>& dst) {
+    CORRLA_HIP(hipMemcpyAsync(dst.p, src.p, (size_t)src.ld * src.cols_alloc * sizeof(T), hipMemcpyDeviceToDevice, stream));
+  }
+  template <class T>
+  void zero_cols(Skinny<T>& s, int64_t c0, int64_t c1) {
+    if (c1 > c0) memset_zero(s.p + c0 * s.ld, (size_t)(c1 - c0) * s.ld * sizeof(T));
+  }
+  template <class T>
+  void store_values(const T* host_src, int64_t n, T* dst, bool dst_is_host) {
+    if (dst_is_host) {
+      std::memcpy(dst, host_src, sizeof(T) * n);
+    } else {
+      CORRLA_HIP(hipMemcpyAsync(dst, host_src, sizeof(T) * n, hipMemcpyHostToDevice, stream));
+      sync();
+    }
+  }
+  // skinny (rows x ncols) -> column-major destination, optionally transposed (ncols x rows)
+  template <class T>
+  void copy_out(const Skinny<T>& src, int64_t ncols, T* dst, int64_t ldd, bool transpose, bool to_host) {
+    const int64_t rows = src.rows;
+    if (!to_host) {
+      launch_copy_out(src.p, src.ld, rows, ncols, dst, ldd, transpose);
+      return;
+    }
+    if (!transpose) {
+      CORRLA_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * sizeof(T), src.p, (size_t)src.ld * sizeof(T),
+                                  (size_t)rows * sizeof(T), (size_t)ncols, hipMemcpyDeviceToHost, stream));
+    } else {
+      T* tmp = (T*)alloc_bytes((size_t)rows * ncols * sizeof(T));
+      launch_copy_out(src.p, src.ld, rows, ncols, tmp, ncols, true);
+      CORRLA_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * sizeof(T), tmp, (size_t)ncols * sizeof(T),
+                                  (size_t)ncols * sizeof(T), (size_t)rows, hipMemcpyDeviceToHost, stream));
+    }
+    sync();
+  }
+  template <class T>
+  void pack_strided(const T* src, int64_t rows, int64_t cols, int64_t rs, int64_t cs, T* dst, int64_t ldd) {
+    const int64_t tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
+    if (tiles_c * tiles_r > 0x7fffffff) throw Error(ST_EINVAL, "problem too large for the launch grid");
+    dim3 grid((unsigned)(tiles_c * tiles_r));
+    hipLaunchKernelGGL((k::pack_strided_kernel<T>), grid, dim3(256), 0, stream, src, rows, cols, rs, cs, dst, ldd, tiles_c);
+    CORRLA_HIP(hipGetLastError());
+  }
+
+  // ---- elementwise / reductions ------------------------------------------------------------
+  template <class T>
+  void sumsq(const Skinny<T>& y, double* out_dev) {
+    const int64_t n = y.ld * y.cols_alloc;  // padding is zero
+    const int blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + 255) / 256));
+    double* partial = (double*)alloc_bytes(sizeof(double) * blocks);
+    hipLaunchKernelGGL((k::sumsq_partial_kernel<T>), dim3(blocks), dim3(256), 0, stream, y.p, n, partial);
+    hipLaunchKernelGGL(k::sum_partials_kernel, dim3(1), dim3(64), 0, stream, partial, blocks, out_dev);
+    CORRLA_HIP(hipGetLastError());
+  }
+  template <class T>
+  void rsqrt_scalar(const double* ss_dev, T* out_dev) {
+    hipLaunchKernelGGL((k::rsqrt_scalar_kernel<T>), dim3(1), dim3(1), 0, stream, ss_dev, out_dev);
+    CORRLA_HIP(hipGetLastError());
+  }
+  template <class T>
+  void scale_inplace(Skinny<T>& y, const T* scale_dev) {
+    const int64_t n = y.ld * y.cols_alloc;
+    const int blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (n + 255) / 256));
+    hipLaunchKernelGGL((k::scale_kernel<T>), dim3(blocks), dim3(256), 0, stream, y.p, n, scale_dev);
+    CORRLA_HIP(hipGetLastError());
+  }
+  template <class T>
+  void fill_normal(T* p, int64_t rows, int64_t cols, int64_t rs, int64_t cs, uint64_t seed, int64_t row0,
+                   int64_t global_cols) {
+    const int64_t n = rows * cols;
+    if (n <= 0) return;
+    const int blocks = (int)std::min<int64_t>(8192, (n + 255) / 256);
+    hipLaunchKernelGGL((k::fill_normal_kernel<T>), dim3(blocks), dim3(256), 0, stream, p, rows, cols, rs, cs, seed, row0,
+                       global_cols, cs <= rs ? 1 : 0);
+    CORRLA_HIP(hipGetLastError());
+  }
+
+  // hipEvent timing of `reps` back-to-back sketch products on this stream
+  template <class F>
+  double time_on_stream(int reps, F&& f) {
+    hipEvent_t e0, e1;
+    CORRLA_HIP(hipEventCreate(&e0));
+    CORRLA_HIP(hipEventCreate(&e1));
+    f();  // warm-up (also pages in the code object)
+    CORRLA_HIP(hipEventRecord(e0, stream));
+    for (int i = 0; i < reps; ++i) f();
+    CORRLA_HIP(hipEventRecord(e1, stream));
+    CORRLA_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CORRLA_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return (double)ms / reps;
+  }
+
+ private:
+  struct Chunk {
+    void* p = nullptr;
+    size_t size = 0, used = 0;
+  };
+  std::vector<Chunk> chunks_;
+  void* zero_page_ = nullptr;
+  int split_nn_override_ = 0, split_tn_override_ = 0;
+
+  static void check_grid(const dim3& g) {
+    if (g.y > 65535u || g.z > 65535u) throw Error(ST_EINVAL, "problem too large for the launch grid");
+  }
+
+  template <class T, int NT>
+  static void set_lds_attr_one() {
+    const int bytes = k::gemm_lds_bytes(NT);
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_nn_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_tn_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  }
+  template <class T>
+  static void set_lds_attrs() {
+    set_lds_attr_one<T, 1>();
+    set_lds_attr_one<T, 2>();
+    set_lds_attr_one<T, 3>();
+    set_lds_attr_one<T, 4>();
+    set_lds_attr_one<T, 5>();
+    set_lds_attr_one<T, 6>();
+    set_lds_attr_one<T, 7>();
+    set_lds_attr_one<T, 8>();
+    set_lds_attr_one<T, 9>();
+  }
+
+  int choose_split(bool tn, int64_t outer_tiles, int nblk, int tiles_total) const {
+    const int ov = tn ? split_tn_override_ : split_nn_override_;
+    int ns;
+    if (ov > 0) {
+      ns = ov;
+    } else {
+      const int64_t wgs = outer_tiles * nblk;
+      if (wgs >= num_cus) return 1;
+      ns = (int)((2 * (int64_t)num_cus + wgs - 1) / wgs);
+      ns = std::min(ns, std::max(1, tiles_total / 4));
+    }
+    ns = std::max(1, std::min(ns, tiles_total));
+    return std::min(ns, 65535);
+  }
+
+  template <class T, int NT>
+  void launch_one(bool tn, dim3 grid, const k::GemmArgs<T>& a) {
+    const int lds = k::gemm_lds_bytes(NT);
+    if (tn)
+      hipLaunchKernelGGL((k::gemm_tn_kernel<T, NT>), grid, dim3(256), lds, stream, a);
+    else
+      hipLaunchKernelGGL((k::gemm_nn_kernel<T, NT>), grid, dim3(256), lds, stream, a);
+  }
+
+  // out (outer_n x L) = scale * op(R) * X; `outer_n` = surviving dimension of R, `red_n` = reduced one
+  template <class T>
+  void launch_gemm(bool tn, const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale_dev, int64_t outer_n,
+                   int64_t red_n) {
+    constexpr int KT = k::MT<T>::KT;
+    constexpr int VEC = k::MT<T>::VEC;
+    const ColBlocking cb = col_blocking(x.cols);
+    if (cb.cols_alloc > x.cols_alloc || cb.cols_alloc > out.cols_alloc)
+      throw Error(ST_EINVAL, "internal: skinny column padding too small for the column blocking");
+    if (out.rows != outer_n || out.ld < outer_n) throw Error(ST_EINVAL, "internal: gemm output shape mismatch");
+    if (((uintptr_t)r.p % 16) || (r.ld % VEC) || (r.cols_readable % VEC) || ((uintptr_t)x.p % 16))
+      throw Error(ST_EINVAL, "internal: operand not 16-byte vector aligned");
+    const int64_t tiles64 = (red_n + KT - 1) / KT;
+    if (tiles64 > 0x7fffffff) throw Error(ST_EINVAL, "reduction dimension too large");
+    const int tiles_total = (int)tiles64;
+    if (x.ld < (int64_t)tiles_total * KT) throw Error(ST_EINVAL, "internal: skinny leading dimension too small");
+    const int64_t outer_tiles = (outer_n + k::kOuterTile - 1) / k::kOuterTile;
+    if (outer_tiles > 0x7fffffff) throw Error(ST_EINVAL, "outer dimension too large");
+    const int nsplit = choose_split(tn, outer_tiles, cb.nblk, tiles_total);
+    k::GemmArgs<T> a;
+    a.r = r.p;
+    a.r_rows = r.rows;
+    a.r_cols = r.cols;
+    a.r_ld = r.ld;
+    a.r_cols_readable = r.cols_readable;
+    a.x = x.p;
+    a.x_ld = x.ld;
+    a.out = out.p;
+    a.out_ld = out.ld;
+    a.scale = scale_dev;
+    a.zero = (const T*)zero_page_;
+    a.tiles_total = tiles_total;
+    a.tiles_per_split = (tiles_total + nsplit - 1) / nsplit;
+    a.nsplit = nsplit;
+    a.slab = nullptr;
+    a.slab_stride = (int64_t)out.ld * cb.cols_alloc;
+    if (nsplit > 1) a.slab = (T*)alloc_bytes((size_t)nsplit * (size_t)a.slab_stride * sizeof(T));
+    dim3 grid((unsigned)outer_tiles, (unsigned)cb.nblk, (unsigned)nsplit);
+    check_grid(grid);
+    switch (cb.nt) {
+      case 1: launch_one<T, 1>(tn, grid, a); break;
+      case 2: launch_one<T, 2>(tn, grid, a); break;
+      case 3: launch_one<T, 3>(tn, grid, a); break;
+      case 4: launch_one<T, 4>(tn, grid, a); break;
+      case 5: launch_one<T, 5>(tn, grid, a); break;
+      case 6: launch_one<T, 6>(tn, grid, a); break;
+      case 7: launch_one<T, 7>(tn, grid, a); break;
+      case 8: launch_one<T, 8>(tn, grid, a); break;
+      case 9: launch_one<T, 9>(tn, grid, a); break;
+      default: throw Error(ST_EINVAL, "internal: bad column blocking");
+    }
+    CORRLA_HIP(hipGetLastError());
+    if (nsplit > 1) {
+      dim3 rg((unsigned)((outer_n + 255) / 256), (unsigned)cb.cols_alloc);
+      check_grid(rg);
+      hipLaunchKernelGGL((k::slab_reduce_kernel<T>), rg, dim3(256), 0, stream, (const T*)a.slab, a.slab_stride, nsplit,
+                         out.p, out.ld, outer_n, cb.cols_alloc, scale_dev);
+      CORRLA_HIP(hipGetLastError());
+    }
+  }
+
+  template <class T>
+  void launch_copy_out(const T* src, int64_t lds_, int64_t rows, int64_t cols, T* dst, int64_t ldd, bool transpose) {
+    const int64_t tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
+    if (tiles_c * tiles_r > 0x7fffffff) throw Error(ST_EINVAL, "problem too large for the launch grid");
+    dim3 grid((unsigned)(tiles_c * tiles_r));
+    hipLaunchKernelGGL((k::copy_out_kernel<T>), grid, dim3(256), 0, stream, src, lds_, rows, cols, dst, ldd,
+                       transpose ? 1 : 0, tiles_c);
+    CORRLA_HIP(hipGetLastError());
+  }
+};
+
+}  // namespace corrla

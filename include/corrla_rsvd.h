@@ -1,0 +1,199 @@
+/*
+ * corrla_rsvd.h -- C ABI of libcorrla_rsvd.so, the MI355X (gfx950) randomized-SVD engine
+ * that drops in behind the RSVD hot path of wgurecky/CORRLA_RS.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * reference checkout).  Signatures use plain pointers and sizes only (no C++/torch types),
+ * so the Rust shim, the Python `corrla_rs` module (ctypes) and bench.py
+ * bind the same symbols.
+ *
+ * Conventions
+ *   - Input A is described exactly like a faer `MatRef<T>`: (ptr, nrows, ncols, row_stride,
+ *     col_stride), strides in ELEMENTS.  numpy C-order arrives as (rs=n, cs=1); a native faer
+ *     `Mat` is column-major (rs=1, cs=m).  A is never modified.
+ *   - Outputs are column-major like the reference's owned `Mat<T>` results
+ *     (random_svd.rs:96-109): U m x k (leading dim ldu >= m), S k values (the k x 1 column),
+ *     Vt k x n (leading dim ldvt >= k).  The caller allocates them.
+ *   - l = min(rank + n_oversamples, min(m, n))   (random_svd.rs:77)
+ *   - Every function returns a corrla_status; corrla_last_error() gives the thread-local
+ *     message.  The reference panics instead (random_svd.rs:98-107, mat_utils.rs:170-171).
+ *   - `_dev` variants take DEVICE pointers (HIP) for A and the outputs and enqueue on the
+ *     context's stream; host variants copy H2D/D2H around the same device path.
+ *   - There is NO CPU fallback: without a usable gfx950 device every compute entry point
+ *     fails with CORRLA_ENODEV.
+ */
+#ifndef CORRLA_RSVD_H
+#define CORRLA_RSVD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct corrla_ctx corrla_ctx;
+
+typedef enum corrla_status {
+  CORRLA_OK = 0,
+  CORRLA_EINVAL = 1,   /* bad argument (rank == 0, rank > min(m,n), null pointer, bad stride ...) */
+  CORRLA_ENOMEM = 2,   /* host or device allocation failed */
+  CORRLA_EHIP = 3,     /* HIP runtime error */
+  CORRLA_ECOMM = 4,    /* RCCL error / communicator not initialised */
+  CORRLA_ENUMERIC = 5, /* non-finite data encountered in the small host factorizations */
+  CORRLA_ENODEV = 6    /* no usable gfx950 device */
+} corrla_status;
+
+/* opts.flags */
+#define CORRLA_OMEGA_ON_DEVICE 0x1u /* opts.omega is a device pointer (only for *_dev entry points) */
+
+/*
+ * Options block.  Zero-initialise, set struct_size = sizeof(corrla_opts).  NULL opts == defaults.
+ *   seed   : seed of the device Philox4x32-10 + Box-Muller generator that replaces
+ *            random_mat_normal (mat_utils.rs:161-175; the reference draws from an unseeded
+ *            thread_rng, so no seed value can reproduce it -- any N(0,1) draw is equivalent).
+ *   omega  : optional sketch matrix that replaces the draw at random_svd.rs:24 -- column-major
+ *            n_t x l, n_t = min(m, n), leading dimension omega_ld (>= n_t), dtype of A.
+ *            This is the test hook that lets the CPU oracle and the GPU share one Omega.
+ */
+typedef struct corrla_opts {
+  uint32_t struct_size;
+  uint32_t flags;
+  uint64_t seed;
+  const void* omega;
+  int64_t omega_ld;
+} corrla_opts;
+
+/* Phase timings of the last rsvd call on a context, milliseconds (host wall clock around
+ * stream-synchronised phases; replaces the SystemTime prints of random_svd.rs:125-140). */
+typedef struct corrla_timings {
+  double total_ms;
+  double sketch_ms;     /* Y = A*Omega                       random_svd.rs:31      */
+  double power_ms;      /* q x {Z = A^T Y, Y = A Z, norm}    random_svd.rs:35-56   */
+  double qr_ms;         /* thin-Q orthonormalisations        random_svd.rs:38,57   */
+  double project_ms;    /* B = Q^T A                         random_svd.rs:80      */
+  double small_svd_ms;  /* svd of the l-wide core            random_svd.rs:89      */
+  double finalize_ms;   /* U = Q*Ut, output copies           random_svd.rs:92-109  */
+  int32_t qr_passes;    /* Gram/whitening passes used by all orthonormalisations */
+  int32_t reserved;
+} corrla_timings;
+
+/* ---- library / context ------------------------------------------------------------- */
+
+/* "corrla_rsvd <version> gfx950" */
+const char* corrla_version(void);
+/* thread-local message of the last failing call on this thread */
+const char* corrla_last_error(void);
+/* number of visible HIP devices (0 when none / no driver) */
+int corrla_device_count(void);
+
+/* One context = one device, one stream, one workspace arena (and optionally one RCCL
+ * communicator).  Replaces faer's process-global Parallelism (mat_utils.rs:31,
+ * random_svd.rs:122).  Calls on one context serialise. */
+corrla_status corrla_ctx_create(int device_ordinal, corrla_ctx** out);
+void corrla_ctx_destroy(corrla_ctx* ctx);
+corrla_status corrla_ctx_synchronize(corrla_ctx* ctx);
+corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out);
+
+/* ---- the hot path: random_svd -------------------------------------------------------
+ * Replaces  pub fn random_svd<T>(a_mat: MatRef<T>, omega_rank, n_iter, n_oversamples)
+ *             -> (Mat<T>, Mat<T>, Mat<T>)                      src/lib_math_utils/random_svd.rs:63-110
+ * and, through it, the pyo3 surface corrla_rs.rsvd(a, n_rank, n_iters, n_oversamples)
+ *                                                              src/lib_math_utils_py.rs:21-36
+ * Host-pointer variants (A, U, S, Vt, opts->omega in host memory). */
+corrla_status corrla_rsvd_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
+                              int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
+                              const corrla_opts* opts, float* u, int64_t ldu, float* s, float* vt, int64_t ldvt);
+corrla_status corrla_rsvd_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
+                              int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
+                              const corrla_opts* opts, double* u, int64_t ldu, double* s, double* vt, int64_t ldvt);
+/* Device-pointer variants: A, U, S, Vt are HIP device pointers on the context's device. */
+corrla_status corrla_rsvd_dev_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
+                                  int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
+                                  const corrla_opts* opts, float* u, int64_t ldu, float* s, float* vt, int64_t ldvt);
+corrla_status corrla_rsvd_dev_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
+                                  int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
+                                  const corrla_opts* opts, double* u, int64_t ldu, double* s, double* vt, int64_t ldvt);
+
+/* ---- the range finder: power_iter ---------------------------------------------------
+ * Replaces  pub fn power_iter<T>(a_mat: MatRef<T>, omega_rank, n_iter) -> Mat<T>
+ *                                                              src/lib_math_utils/random_svd.rs:15-59
+ * `width` is the ALREADY OVERSAMPLED sketch width (the reference's `omega_rank` argument of
+ * power_iter), width <= n.  Q: column-major m x width, leading dimension ldq.  Requires m >= 1,
+ * n >= 1 (no fat->tall transpose here, exactly as in the reference). */
+corrla_status corrla_power_iter_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
+                                    int64_t col_stride, int64_t width, int64_t n_iter, const corrla_opts* opts,
+                                    float* q, int64_t ldq);
+corrla_status corrla_power_iter_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
+                                    int64_t col_stride, int64_t width, int64_t n_iter, const corrla_opts* opts,
+                                    double* q, int64_t ldq);
+corrla_status corrla_power_iter_dev_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
+                                        int64_t col_stride, int64_t width, int64_t n_iter, const corrla_opts* opts,
+                                        float* q, int64_t ldq);
+corrla_status corrla_power_iter_dev_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
+                                        int64_t col_stride, int64_t width, int64_t n_iter, const corrla_opts* opts,
+                                        double* q, int64_t ldq);
+
+/* ---- the GEMM shim: par_matmul_helper -----------------------------------------------
+ * Replaces  par_matmul_helper(res, lhs, rhs, beta, n_threads)  src/lib_math_utils/mat_utils.rs:20-33
+ * for the two shapes the hot path uses it with (random_svd.rs:42-51): a large strided
+ * matrix A (m x n, any of the two unit-stride layouts) times / transposed-times a skinny
+ * column-major matrix.  res is OVERWRITTEN (alpha = None), res = beta * op(A) * X.
+ *   trans == 0 : res (m x l) = beta * A   * X (n x l)
+ *   trans == 1 : res (n x l) = beta * A^T * X (m x l)
+ * X and res are column-major with leading dimensions ldx / ldres.  DEVICE pointers. */
+corrla_status corrla_matmul_dev_f32(corrla_ctx* ctx, int trans, const float* a, int64_t m, int64_t n,
+                                    int64_t row_stride, int64_t col_stride, const float* x, int64_t ldx, int64_t l,
+                                    float beta, float* res, int64_t ldres);
+corrla_status corrla_matmul_dev_f64(corrla_ctx* ctx, int trans, const double* a, int64_t m, int64_t n,
+                                    int64_t row_stride, int64_t col_stride, const double* x, int64_t ldx, int64_t l,
+                                    double beta, double* res, int64_t ldres);
+
+/* ---- the Gaussian generator: random_mat_normal --------------------------------------
+ * Replaces  random_mat_normal<T>(n_rows, n_cols)               src/lib_math_utils/mat_utils.rs:161-175
+ * Fills a DEVICE matrix with i.i.d. N(0,1) from a counter-based Philox4x32-10 + Box-Muller
+ * stream: element (i, j) of the logical matrix depends only on (seed, (row0 + i) * global_cols + j),
+ * so any row shard generates its own rows bit-identically.  Storage strides in elements. */
+corrla_status corrla_fill_normal_dev_f32(corrla_ctx* ctx, float* p, int64_t rows, int64_t cols, int64_t row_stride,
+                                         int64_t col_stride, uint64_t seed, int64_t row0, int64_t global_cols);
+corrla_status corrla_fill_normal_dev_f64(corrla_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t row_stride,
+                                         int64_t col_stride, uint64_t seed, int64_t row0, int64_t global_cols);
+
+/* ---- measurement hook ---------------------------------------------------------------
+ * Times `reps` back-to-back launches of the sketch GEMM Y = A * X (random_svd.rs:31) with
+ * hipEvents recorded on the context's stream (the stream the kernel runs on) and returns the
+ * average kernel-sequence duration in milliseconds.  DEVICE pointers, layouts as in
+ * corrla_matmul_dev_*.  Used by bench.py for roofline.achieved. */
+corrla_status corrla_time_sketch_dev_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
+                                         int64_t col_stride, const float* x, int64_t ldx, int64_t l, float* y,
+                                         int64_t ldy, int reps, double* avg_ms);
+corrla_status corrla_time_sketch_dev_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
+                                         int64_t col_stride, const double* x, int64_t ldx, int64_t l, double* y,
+                                         int64_t ldy, int reps, double* avg_ms);
+
+/* ---- multi-GPU: row-sharded tall matrices ---------------------
+ * One process per GPU.  Rank 0 calls corrla_comm_unique_id, the 128 bytes are broadcast by the
+ * host program (torch.distributed / MPI / a file), then every rank calls corrla_ctx_comm_init.
+ * The communicator is RCCL; collectives are enqueued on the context's stream. */
+#define CORRLA_UNIQUE_ID_BYTES 128
+corrla_status corrla_comm_unique_id(void* out128);
+corrla_status corrla_ctx_comm_init(corrla_ctx* ctx, const void* unique_id128, int rank, int nranks);
+
+/* Row-sharded random_svd: this rank holds rows [row0, row0 + m_local) of the TALL matrix
+ * A (m_global x n, m_global >= n), unit column stride or unit row stride as above.
+ * U_local: m_local x k (this rank's rows of U); S and Vt are replicated on every rank.
+ * Exchanges per call: q+1 all-reduces of n x l (Z and B^T), the l x l Gram all-reduces of the
+ * orthonormalisations, one scalar per power iteration.  DEVICE pointers. */
+corrla_status corrla_rsvd_sharded_dev_f32(corrla_ctx* ctx, const float* a_local, int64_t m_local, int64_t n,
+                                          int64_t row_stride, int64_t col_stride, int64_t rank, int64_t n_iter,
+                                          int64_t n_oversamples, const corrla_opts* opts, float* u_local, int64_t ldu,
+                                          float* s, float* vt, int64_t ldvt);
+corrla_status corrla_rsvd_sharded_dev_f64(corrla_ctx* ctx, const double* a_local, int64_t m_local, int64_t n,
+                                          int64_t row_stride, int64_t col_stride, int64_t rank, int64_t n_iter,
+                                          int64_t n_oversamples, const corrla_opts* opts, double* u_local, int64_t ldu,
+                                          double* s, double* vt, int64_t ldvt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORRLA_RSVD_H */

@@ -1,0 +1,256 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into libcorrla_rsvd.so, never shipped.
+//
+// A host emulation of the device backend interface (hip_backend.hpp) so that the `-m "not gpu"`
+// tests can drive the REAL algorithm driver (corrla_rs_amd/csrc/driver.hpp) and the REAL C-ABI glue
+// (capi_impl.hpp: validation, fat/tall + stride classification, output orientation, the
+// orthonormalisation pass logic, the sharded exchange points) on a machine without a GPU.
+// It restates nothing from the reference and is not an alternative product path: the product
+// library has no CPU fallback and returns CORRLA_ENODEV without a gfx950 device.
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../corrla_rs_amd/csrc/capi_impl.hpp"
+
+using namespace corrla;
+
+typedef void (*emu_allreduce_fn)(void* buf, uint64_t count, int is_f64);
+static emu_allreduce_fn g_allreduce = nullptr;
+static int g_nranks = 1;
+
+static inline void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+static inline float normal_f32(uint64_t idx, uint64_t seed) {
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), 0u, 0u};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return std::sqrt(-2.0f * std::log(u1)) * (float)std::cos(2.0 * M_PI * (double)u2);
+}
+static inline double normal_f64(uint64_t idx, uint64_t seed) {
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), 0u, 0u};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint64_t a = (((uint64_t)c[0] << 32) | c[1]) >> 11;
+  const uint64_t b = (((uint64_t)c[2] << 32) | c[3]) >> 11;
+  const double u1 = ((double)a + 0.5) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)b + 0.5) * (1.0 / 9007199254740992.0);
+  return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
+}
+template <class T>
+static inline T normal_from_index(uint64_t idx, uint64_t seed);
+template <>
+inline float normal_from_index<float>(uint64_t i, uint64_t s) { return normal_f32(i, s); }
+template <>
+inline double normal_from_index<double>(uint64_t i, uint64_t s) { return normal_f64(i, s); }
+
+class EmuDev {
+ public:
+  std::vector<std::unique_ptr<char[]>> blocks;
+  int nranks() const { return g_nranks; }
+  void begin_call() { blocks.clear(); }
+  void end_call() {}
+  void sync() {}
+  void* alloc_bytes(size_t bytes) {
+    blocks.emplace_back(new char[bytes + 64]);
+    char* p = blocks.back().get();
+    p += (64 - ((uintptr_t)p % 64)) % 64;
+    return p;
+  }
+  void memset_zero(void* p, size_t bytes) { std::memset(p, 0, bytes); }
+  template <class T>
+  Skinny<T> alloc_skinny(int64_t rows, int64_t cols) {
+    Skinny<T> s;
+    s.rows = rows;
+    s.cols = cols;
+    s.ld = round_up(std::max<int64_t>(rows, 1), kLdPad);
+    s.cols_alloc = col_blocking(cols).cols_alloc;
+    const size_t bytes = (size_t)s.ld * s.cols_alloc * sizeof(T);
+    s.p = (T*)alloc_bytes(bytes);
+    std::memset(s.p, 0, bytes);
+    return s;
+  }
+  double* alloc_f64(int n) {
+    double* p = (double*)alloc_bytes(sizeof(double) * n);
+    std::memset(p, 0, sizeof(double) * n);
+    return p;
+  }
+  template <class T>
+  T* alloc_scalar(int n) {
+    T* p = (T*)alloc_bytes(sizeof(T) * n);
+    std::memset(p, 0, sizeof(T) * n);
+    return p;
+  }
+  template <class T>
+  void h2d_2d(T* dst, int64_t dp, const T* src, int64_t sp, int64_t width, int64_t rows) {
+    for (int64_t r = 0; r < rows; ++r) std::memcpy(dst + r * dp, src + r * sp, sizeof(T) * width);
+  }
+  // Same contracts as the HIP kernels, including the padded-column writes.
+  template <class T>
+  void gemm_nn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale) {
+    if (x.rows != r.cols) throw Error(ST_EINVAL, "gemm_nn: inner dimensions differ");
+    const ColBlocking cb = col_blocking(x.cols);
+    if (cb.cols_alloc > x.cols_alloc || cb.cols_alloc > out.cols_alloc) throw Error(ST_EINVAL, "emu: column padding");
+    if (out.rows != r.rows) throw Error(ST_EINVAL, "emu: gemm output shape mismatch");
+    const double sc = scale ? (double)*scale : 1.0;
+    for (int64_t c = 0; c < cb.cols_alloc; ++c)
+      for (int64_t i = 0; i < r.rows; ++i) {
+        double s = 0.0;
+        for (int64_t kk = 0; kk < r.cols; ++kk) s += (double)r.p[i * r.ld + kk] * (double)x.p[c * x.ld + kk];
+        out.p[c * out.ld + i] = (T)(s * sc);
+      }
+  }
+  template <class T>
+  void gemm_tn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale) {
+    if (x.rows != r.rows) throw Error(ST_EINVAL, "gemm_tn: inner dimensions differ");
+    const ColBlocking cb = col_blocking(x.cols);
+    if (cb.cols_alloc > x.cols_alloc || cb.cols_alloc > out.cols_alloc) throw Error(ST_EINVAL, "emu: column padding");
+    if (out.rows != r.cols) throw Error(ST_EINVAL, "emu: gemm output shape mismatch");
+    const double sc = scale ? (double)*scale : 1.0;
+    for (int64_t c = 0; c < cb.cols_alloc; ++c)
+      for (int64_t j = 0; j < r.cols; ++j) {
+        double s = 0.0;
+        for (int64_t i = 0; i < r.rows; ++i) s += (double)r.p[i * r.ld + j] * (double)x.p[c * x.ld + i];
+        out.p[c * out.ld + j] = (T)(s * sc);
+      }
+  }
+  template <class T>
+  void allreduce(T* p, size_t count) {
+    if (g_nranks <= 1) return;
+    if (!g_allreduce) throw Error(ST_ECOMM, "emu: no allreduce callback");
+    g_allreduce(p, count, sizeof(T) == 8);
+  }
+  void allreduce_f64(double* p, size_t count) { allreduce<double>(p, count); }
+  template <class T>
+  void download_skinny(const Skinny<T>& s, int64_t rows, int64_t cols, double* host) {
+    for (int64_t j = 0; j < cols; ++j)
+      for (int64_t i = 0; i < rows; ++i) host[j * rows + i] = (double)s.p[j * s.ld + i];
+  }
+  template <class T>
+  void upload_skinny(const double* host, int64_t rows, int64_t cols, int64_t ldh, Skinny<T>& dst) {
+    std::memset(dst.p, 0, (size_t)dst.ld * dst.cols_alloc * sizeof(T));
+    for (int64_t j = 0; j < cols; ++j)
+      for (int64_t i = 0; i < rows; ++i) dst.p[j * dst.ld + i] = (T)host[j * ldh + i];
+  }
+  template <class T>
+  void upload_skinny_native(const T* host, int64_t ldh, Skinny<T>& dst) {
+    for (int64_t j = 0; j < dst.cols; ++j) std::memcpy(dst.p + j * dst.ld, host + j * ldh, sizeof(T) * dst.rows);
+  }
+  template <class T>
+  void copy_in_skinny(const T* src, int64_t lds, Skinny<T>& dst) { upload_skinny_native(src, lds, dst); }
+  template <class T>
+  void copy_skinny(const Skinny<T>& src, Skinny<T>& dst) {
+    std::memcpy(dst.p, src.p, (size_t)src.ld * src.cols_alloc * sizeof(T));
+  }
+  template <class T>
+  void zero_cols(Skinny<T>& s, int64_t c0, int64_t c1) {
+    if (c1 > c0) std::memset(s.p + c0 * s.ld, 0, (size_t)(c1 - c0) * s.ld * sizeof(T));
+  }
+  template <class T>
+  void store_values(const T* src, int64_t n, T* dst, bool) { std::memcpy(dst, src, sizeof(T) * n); }
+  template <class T>
+  void copy_out(const Skinny<T>& src, int64_t ncols, T* dst, int64_t ldd, bool transpose, bool) {
+    for (int64_t c = 0; c < ncols; ++c)
+      for (int64_t r = 0; r < src.rows; ++r) {
+        if (transpose)
+          dst[r * ldd + c] = src.p[c * src.ld + r];
+        else
+          dst[c * ldd + r] = src.p[c * src.ld + r];
+      }
+  }
+  template <class T>
+  void pack_strided(const T* src, int64_t rows, int64_t cols, int64_t rs, int64_t cs, T* dst, int64_t ldd) {
+    for (int64_t r = 0; r < rows; ++r)
+      for (int64_t c = 0; c < cols; ++c) dst[r * ldd + c] = src[r * rs + c * cs];
+  }
+  template <class T>
+  void sumsq(const Skinny<T>& y, double* out) {
+    double s = 0.0;
+    for (int64_t i = 0; i < y.ld * y.cols_alloc; ++i) s += (double)y.p[i] * (double)y.p[i];
+    *out = s;
+  }
+  template <class T>
+  void rsqrt_scalar(const double* ss, T* out) { *out = (T)(*ss > 0.0 ? 1.0 / std::sqrt(*ss) : 0.0); }
+  template <class T>
+  void scale_inplace(Skinny<T>& y, const T* sc) {
+    for (int64_t i = 0; i < y.ld * y.cols_alloc; ++i) y.p[i] *= *sc;
+  }
+  template <class T>
+  void fill_normal(T* p, int64_t rows, int64_t cols, int64_t rs, int64_t cs, uint64_t seed, int64_t row0, int64_t gcols) {
+    for (int64_t i = 0; i < rows; ++i)
+      for (int64_t j = 0; j < cols; ++j) p[i * rs + j * cs] = normal_from_index<T>((uint64_t)((row0 + i) * gcols + j), seed);
+  }
+};
+
+extern "C" {
+const char* corrla_emu_last_error(void) { return last_error_slot().c_str(); }
+void corrla_emu_set_comm(emu_allreduce_fn fn, int nranks) {
+  g_allreduce = fn;
+  g_nranks = nranks;
+}
+#define EMU_DEFINE(SUF, T)                                                                                             \
+  int corrla_emu_rsvd_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank, int64_t n_iter,    \
+                            int64_t p, const corrla_opts* o, T* u, int64_t ldu, T* s, T* vt, int64_t ldvt,             \
+                            int* qr_passes) {                                                                          \
+    return guarded([&] {                                                                                               \
+      EmuDev dev;                                                                                                      \
+      Timings tm;                                                                                                      \
+      rsvd_entry<EmuDev, T>(dev, true, false, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt, &tm, false);   \
+      if (qr_passes) *qr_passes = tm.qr_passes;                                                                        \
+    });                                                                                                                \
+  }                                                                                                                    \
+  int corrla_emu_rsvd_sharded_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank,            \
+                                    int64_t n_iter, int64_t p, const corrla_opts* o, T* u, int64_t ldu, T* s, T* vt,   \
+                                    int64_t ldvt) {                                                                    \
+    return guarded([&] {                                                                                               \
+      EmuDev dev;                                                                                                      \
+      rsvd_entry<EmuDev, T>(dev, true, true, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt, nullptr,        \
+                            false);                                                                                    \
+    });                                                                                                                \
+  }                                                                                                                    \
+  int corrla_emu_power_iter_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t width,             \
+                                  int64_t n_iter, const corrla_opts* o, T* q, int64_t ldq) {                           \
+    return guarded([&] {                                                                                               \
+      EmuDev dev;                                                                                                      \
+      power_iter_entry<EmuDev, T>(dev, true, a, m, n, rs, cs, width, n_iter, o, q, ldq);                               \
+    });                                                                                                                \
+  }                                                                                                                    \
+  int corrla_emu_matmul_##SUF(int trans, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, const T* x,         \
+                              int64_t ldx, int64_t l, T beta, T* res, int64_t ldres) {                                 \
+    return guarded([&] {                                                                                               \
+      EmuDev dev;                                                                                                      \
+      matmul_entry<EmuDev, T>(dev, trans, a, m, n, rs, cs, x, ldx, l, beta, res, ldres);                               \
+    });                                                                                                                \
+  }                                                                                                                    \
+  int corrla_emu_fill_normal_##SUF(T* p, int64_t rows, int64_t cols, int64_t rs, int64_t cs, uint64_t seed,            \
+                                   int64_t row0, int64_t gcols) {                                                      \
+    return guarded([&] {                                                                                               \
+      EmuDev dev;                                                                                                      \
+      dev.fill_normal(p, rows, cols, rs, cs, seed, row0, gcols);                                                       \
+    });                                                                                                                \
+  }
+EMU_DEFINE(f32, float)
+EMU_DEFINE(f64, double)
+
+// direct hooks for the host-side small dense routines (product code in small_linalg.hpp)
+int corrla_emu_chol_upper(int n, double* g, int ld, double piv_rel, double* min_ratio) {
+  return small::chol_upper(n, g, ld, piv_rel, min_ratio) ? 1 : 0;
+}
+void corrla_emu_triu_inverse(int n, double* r, int ld) { small::triu_inverse(n, r, ld); }
+int corrla_emu_jacobi_svd(int n, const double* c, int ld, double* u, double* s, double* v, double tol) {
+  return small::jacobi_svd(n, c, ld, u, s, v, tol);
+}
+}

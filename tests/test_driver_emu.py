@@ -1,0 +1,163 @@
+"""Host logic of the product (driver.hpp + capi_impl.hpp + small_linalg.hpp) exercised through the
+test-only emulation backend, against the CPU oracle.  No GPU, no compute call into libcorrla_rsvd.so."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import rsvd_oracle as orc
+from tests.conftest import golden_names
+from tests.emu_harness import emu, emu_fill_normal, emu_matmul, emu_power_iter, emu_rsvd
+from tests.helpers import align_signs, check_factorization, load_golden, orth_err
+
+
+def _compare(a, k, q, p, omega, dtype, s_rtol, rec_rtol):
+    a = a.astype(dtype)
+    om = omega.astype(dtype)
+    u, s, vt = emu_rsvd(a, k, q, p, omega=om)
+    uo, so, vto = orc.random_svd(a, k, q, p, omega=om)
+    check_factorization(a, u, s, vt, k, 0)
+    s1 = max(float(so[0, 0]), 1e-300)
+    assert np.max(np.abs(s.ravel().astype(np.float64) - so.ravel())) <= s_rtol * s1
+    # relerr parity: within 1e-5 of the CPU restatement on the same A and Omega
+    assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-5
+    # rank-k reconstructions agree (sign-free)
+    rec = (u.astype(np.float64) * s.ravel()) @ vt.astype(np.float64)
+    reco = (uo.astype(np.float64) * so.ravel()) @ vto.astype(np.float64)
+    assert np.linalg.norm(rec - reco) <= rec_rtol * max(np.linalg.norm(reco), 1e-300)
+    nnz = int(np.sum(so.ravel() > 1e-5 * s1))
+    eps = np.finfo(dtype).eps
+    assert orth_err(u[:, :nnz]) <= 200 * eps * np.sqrt(a.shape[0])
+    assert orth_err(vt[:nnz, :].T) <= 200 * eps * np.sqrt(a.shape[1])
+    return u, s, vt
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_emu_driver_vs_oracle_golden(name, dtype):
+    g = load_golden(name)
+    f64 = dtype == np.float64
+    tight = name not in ("lowrank256x96", "fat20x500_pod", "rankdef96x40")
+    s_rtol = (1e-10 if f64 else 2e-5) if tight else (1e-7 if f64 else 2e-3)
+    rec_rtol = (1e-8 if f64 else 1e-3) if tight else (1e-6 if f64 else 2e-2)
+    u, s, vt = _compare(g["A"], g["k"], g["q"], g["p"], g["omega"], dtype, s_rtol, rec_rtol)
+    if name.startswith("known5x5"):
+        # random_svd.rs:170-195
+        assert np.allclose(s.ravel(), orc.KNOWN_ANSWER_S[: g["k"]], atol=1e-3)
+
+
+@pytest.mark.parametrize("order", ["C", "F", "strided", "strided_cols"])
+@pytest.mark.parametrize("shape", [(70, 33), (33, 70), (64, 64), (1, 9), (9, 1), (5, 5)])
+def test_emu_layouts_and_shapes(order, shape):
+    rng = np.random.default_rng(7)
+    m, n = shape
+    base = rng.standard_normal((2 * m, 2 * n))
+    if order == "C":
+        a = np.ascontiguousarray(base[:m, :n])
+    elif order == "F":
+        a = np.asfortranarray(base[:m, :n])
+    elif order == "strided":
+        a = base[::2, ::2]
+    else:
+        a = base[:m, ::2]
+    k = max(1, min(m, n) // 3)
+    q, p = 2, 4
+    nt = min(m, n)
+    l = min(k + p, nt)
+    omega = rng.standard_normal((nt, l))
+    u, s, vt = emu_rsvd(a, k, q, p, omega=omega)
+    uo, so, vto = orc.random_svd(np.array(a), k, q, p, omega=omega)
+    assert np.allclose(s, so, rtol=0, atol=1e-9 * so[0, 0])
+    assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) < 1e-9
+
+
+def test_emu_power_iter_matches_oracle_range():
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((120, 40))
+    om = rng.standard_normal((40, 12))
+    for q in (0, 2, 5):
+        qe = emu_power_iter(a, 12, q, omega=om)
+        qo = orc.power_iter(a, om, q)
+        assert orth_err(qe) < 1e-12
+        # same range: projectors agree
+        assert np.linalg.norm(qe @ qe.T - qo @ qo.T) < 1e-8
+
+
+def test_emu_invalid_arguments():
+    a = np.ones((6, 4))
+    with pytest.raises(ValueError):
+        emu_rsvd(a, 5, 1, 2)   # rank > min(m,n): reference panics (random_svd.rs:98-107)
+    with pytest.raises(ValueError):
+        emu_rsvd(a, 0, 1, 2)
+    with pytest.raises(ValueError):
+        emu_rsvd(a, 2, -1, 2)
+
+
+def test_emu_zero_matrix():
+    u, s, vt = emu_rsvd(np.zeros((12, 7)), 3, 2, 2, omega=np.ones((7, 5)))
+    assert np.all(s == 0) and np.all(np.isfinite(u)) and np.all(np.isfinite(vt))
+
+
+def test_emu_qr_passes_well_conditioned():
+    # well-conditioned sketch: 2 Gram passes per orthonormalisation (Y and B^T) = 4
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((300, 80))
+    *_, passes = emu_rsvd(a, 8, 2, 8, omega=rng.standard_normal((80, 16)), return_passes=True)
+    assert passes == 4
+
+
+def test_emu_matmul_known_answers():
+    # mat_utils.rs:642-684
+    d = np.load(__import__("os").path.join(__import__("tests.helpers", fromlist=["x"]).GOLDEN_DIR, "matmul_known.npz"))
+    assert np.allclose(emu_matmul(d["lhs"], d["rhs_vec"], False), d["out_vec"], atol=1e-6)
+    assert np.allclose(emu_matmul(d["lhs"], d["rhs_mat"], False), d["out_mat"], atol=1e-6)
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((37, 21))
+    x = rng.standard_normal((37, 5))
+    assert np.allclose(emu_matmul(a, x, True, beta=0.5), 0.5 * a.T @ x, atol=1e-12)
+    assert np.allclose(emu_matmul(np.asfortranarray(a), x, True), a.T @ x, atol=1e-12)
+
+
+def test_small_linalg_routines():
+    e = emu()
+    rng = np.random.default_rng(11)
+    n = 37
+    x = rng.standard_normal((90, n))
+    g = np.asfortranarray(x.T @ x)
+    r = g.copy(order="F")
+    mr = C.c_double()
+    ok = e.corrla_emu_chol_upper(n, r.ctypes.data_as(C.c_void_p), n, C.c_double(1e-14), C.byref(mr))
+    assert ok == 1 and np.allclose(np.triu(r).T @ np.triu(r), g, atol=1e-10)
+    assert np.allclose(np.tril(r, -1), 0)
+    rinv = r.copy(order="F")
+    e.corrla_emu_triu_inverse(n, rinv.ctypes.data_as(C.c_void_p), n)
+    assert np.allclose(np.triu(rinv) @ np.triu(r), np.eye(n), atol=1e-9)
+    # singular Gram -> Cholesky reports failure
+    gs = np.asfortranarray(np.ones((4, 4)))
+    assert e.corrla_emu_chol_upper(4, gs.ctypes.data_as(C.c_void_p), 4, C.c_double(1e-12), C.byref(mr)) == 0
+    # Jacobi SVD incl. a rank-deficient matrix
+    for c in (rng.standard_normal((n, n)), rng.standard_normal((n, 5)) @ rng.standard_normal((5, n))):
+        cf = np.asfortranarray(c)
+        u = np.empty((n, n), order="F"); v = np.empty((n, n), order="F"); s = np.empty(n)
+        e.corrla_emu_jacobi_svd.restype = C.c_int
+        sweeps = e.corrla_emu_jacobi_svd(n, cf.ctypes.data_as(C.c_void_p), n, u.ctypes.data_as(C.c_void_p),
+                                         s.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), C.c_double(1e-15))
+        assert 0 < sweeps < 40
+        assert np.allclose((u * s) @ v.T, c, atol=1e-10)
+        assert np.allclose(s, np.linalg.svd(c, compute_uv=False), atol=1e-10)
+        assert np.all(np.diff(s) <= 1e-12)
+        assert orth_err(v) < 1e-12
+
+
+def test_fill_normal_is_counter_based_and_standard_normal():
+    full = emu_fill_normal(64, 48, seed=20241008)
+    # any row shard regenerates its rows bit-identically (SURVEY 8d synthetic inputs)
+    shard = emu_fill_normal(16, 48, seed=20241008, row0=32, global_cols=48)
+    assert np.array_equal(full[32:48], shard)
+    colmajor = emu_fill_normal(64, 48, seed=20241008, order="F")
+    assert np.array_equal(full, colmajor)
+    big = emu_fill_normal(400, 500, seed=1)
+    assert abs(big.mean()) < 0.01 and abs(big.std() - 1) < 0.01
+    from scipy import stats
+    assert stats.kstest(big.ravel()[:50000], "norm").pvalue > 1e-3
+    assert not np.array_equal(emu_fill_normal(8, 8, seed=1), emu_fill_normal(8, 8, seed=2))
