@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- RSVD throughput on MI355X (BASELINE.json metric: "RSVD GFLOP/s on 16k x 16k f32 rank-128;
+% of MFMA peak at 1/2/4/8 GPUs").
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete random_svd (random_svd.rs:63-110) of the synthetic matrix, inputs resident in
+HBM when the timed region starts: A ~ N(0,1) generated on device (Philox4x32-10 + Box-Muller, seed
+20241008, counter = row * n + col), Omega drawn on device by the library (seed 1).
+N = 1: BASELINE config 2 -- 16384 x 16384 f32, rank 128, 2 power iterations, 10 oversamples.
+N > 1: the same block per GPU, row-sharded (weak scaling): rank r holds rows [16384 r, 16384 (r+1)) of the
+       (16384 N) x 16384 matrix; RCCL all-reduces of the n x l and l x l factors.
+value = algorithmic GFLOP/s over all ranks: ((4q+4) m n l + 2 m l^2 + (4 m l^2 - 4/3 l^3)) / step time,
+with the UNPADDED l = 138; the host-side l x l SVD is inside the timed step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M_PER_GPU, N_COLS, RANK, N_ITER, N_OVER = 16384, 16384, 128, 2, 10
+SEED_A, SEED_OMEGA = 20241008, 1
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak
+CPU_SAMPLE = 8192              # cpu_baseline runs the oracle on a CPU_SAMPLE^2 corner of the same workload
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(a_dev, l):
+    """Reference CPU path beside the GPU number: the oracle (numpy restatement of random_svd.rs) on the
+    GPU box's host cores, bounded sample, all cores (numpy/OpenBLAS threading)."""
+    import numpy as np
+    from oracle import rsvd_oracle as orc
+    s = CPU_SAMPLE
+    a = a_dev[:s, :s].contiguous().cpu().numpy()
+    rng = np.random.default_rng(SEED_OMEGA)
+    omega = rng.standard_normal((s, l)).astype(np.float32)
+    orc.random_svd(a[:1024, :1024], RANK, N_ITER, N_OVER, omega=omega[:1024])  # warm the BLAS threads
+    t0 = time.perf_counter()
+    orc.random_svd(a, RANK, N_ITER, N_OVER, omega=omega)
+    dt = time.perf_counter() - t0
+    flops = orc.algorithmic_flops(s, s, RANK, N_ITER, N_OVER)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return {"value": round(flops / dt / 1e9, 2), "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/rsvd_oracle.py random_svd on the {s}x{s} f32 corner of the same matrix, rank {RANK}, "
+                      f"q={N_ITER}, p={N_OVER}, {dt:.2f} s, numpy/OpenBLAS threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import corrla_rs_amd as cr
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    ctx = cr.Context(local_rank)
+    if world > 1:
+        ids = [cr.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], rank, world)
+
+    m_loc, n, k, q, p = M_PER_GPU, N_COLS, RANK, N_ITER, N_OVER
+    l = min(k + p, n)
+    a = torch.empty((m_loc, n), dtype=torch.float32, device=dev)
+    ctx.fill_normal(a, seed=SEED_A, row0=rank * m_loc, global_cols=n)
+    m_glob = m_loc * world
+    flops = cr.algorithmic_flops(m_glob, n, k, q, p)
+
+    def step():
+        if world > 1:
+            return ctx.rsvd_sharded(a, k, q, p, seed=SEED_OMEGA)
+        return ctx.rsvd(a, k, q, p, seed=SEED_OMEGA)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = flops * args.steps / dt / 1e9
+
+    # accuracy gate reported with the timing (rank-local orthonormality; full parity lives in tests/)
+    u, s, vt = out
+    tm = ctx.timings()
+
+    result = None
+    if rank == 0:
+        # dominant kernel: the sketch GEMM Y = A * Omega (random_svd.rs:31), hipEvents on the library's stream
+        om = torch.empty((n, l), dtype=torch.float32, device=dev)
+        ctx.fill_normal(om, seed=SEED_OMEGA)
+        sk_ms, _ = ctx.time_sketch(a, om, reps=20)
+        sk_flops = 2.0 * m_loc * n * l   # algorithmic: unpadded l = 138 (the kernel computes 144 columns)
+        achieved = sk_flops / (sk_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "gemm_nn_kernel<float,9> (sketch Y = A*Omega, 16384x16384x138)",
+                    "avg_launch_ms": round(sk_ms, 4),
+                    "hbm_GBps_on_A_read": round(m_loc * n * 4 / (sk_ms * 1e-3) / 1e9, 1)}
+        log(f"[bench] step {ms_per_step:.3f} ms  value {value:.0f} GFLOP/s  sketch {sk_ms:.3f} ms = {achieved:.1f} TF "
+            f"({100 * achieved / PEAK_F32_MFMA_TFLOPS:.1f}% of f32 MFMA peak)")
+        log(f"[bench] last-call phases (ms): {json.dumps({k_: round(v, 3) if isinstance(v, float) else v for k_, v in tm.items()})}")
+        eye = torch.eye(k, dtype=torch.float64, device=dev)
+        vo = (vt.double() @ vt.double().t() - eye).abs().max().item()
+        log(f"[bench] s[0]={s[0, 0].item():.3f} s[k-1]={s[-1, 0].item():.3f}  |VVt-I|max={vo:.2e}")
+        result = {
+            "metric": "RSVD GFLOP/s on 16k x 16k f32 rank-128",
+            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"random_svd of a {m_glob}x{n} f32 Gaussian matrix ({m_loc}x{n} per GPU, row-sharded), "
+                                   f"rank={k}, n_iter={q}, n_oversamples={p} (l={l}); BASELINE.json configs[1]",
+                       "m": m_glob, "n": n, "rank": k, "n_iter": q, "n_oversamples": p,
+                       "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
+                       "algorithmic_flops_per_step": flops,
+                       "pct_of_f32_mfma_peak_whole_job": round(100 * value / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 2)},
+            "roofline": roofline,
+            "phases_ms_last_step": {k_: (round(v, 3) if isinstance(v, float) else v) for k_, v in tm.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(a, l)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

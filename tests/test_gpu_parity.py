@@ -1,0 +1,290 @@
+"""GPU parity tests: the HIP path (through the C ABI of libcorrla_rsvd.so) against the CPU oracle on
+the same seeded inputs and the same Omega, against the committed golden fixtures, and -- at
+BASELINE.json's full sizes -- through size-independent properties.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+from oracle import rsvd_oracle as orc
+from tests.conftest import golden_names
+from tests.helpers import check_factorization, load_golden, orth_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import corrla_rs_amd as cr
+    return cr.Context(0)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_native_library_is_the_path(ctx):
+    from corrla_rs_amd import _lib
+    lib = _lib.load()
+    assert b"gfx950" in lib.corrla_version()
+    assert lib.corrla_device_count() >= 1
+
+
+# ---- the GEMM shim (par_matmul_helper, mat_utils.rs:20-33) --------------------------------------
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("layout", ["row", "col"])
+@pytest.mark.parametrize("shape_l", [(64, 64, 16), (200, 136, 24), (333, 130, 1), (130, 333, 40), (1000, 72, 138),
+                                     (72, 1000, 150), (4, 4, 3), (257, 63, 17), (2048, 1024, 138), (5000, 36, 74)])
+def test_matmul_both_ops(ctx, torch, dtype, layout, shape_l):
+    m, n, l = shape_l
+    dt = getattr(torch, dtype)
+    g = torch.Generator(device="cuda").manual_seed(m * 1000 + n)
+    a = torch.randn((m, n), dtype=dt, device="cuda", generator=g)
+    if layout == "col":
+        a = a.t().contiguous().t()  # same values, column-major memory
+    tol = 2e-5 if dtype == "float32" else 1e-12
+    for trans in (False, True):
+        x = torch.randn(((m if trans else n), l), dtype=dt, device="cuda", generator=g)
+        res = ctx.matmul(a, x, trans=trans, beta=1.0)
+        ref = (a.double().t() if trans else a.double()) @ x.double()
+        scale = ref.abs().max().item() + 1e-30
+        err = (res.double() - ref).abs().max().item() / scale
+        assert err < tol, (trans, err)
+    # beta scaling (res = beta * lhs * rhs, alpha=None => overwrite)
+    x = torch.randn((n, l), dtype=dt, device="cuda", generator=g)
+    res = ctx.matmul(a, x, trans=False, beta=0.25)
+    ref = 0.25 * (a.double() @ x.double())
+    assert (res.double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-30) < tol
+
+
+def test_matmul_known_answers(ctx, torch):
+    # mat_utils.rs:642-684
+    import os
+    from tests.helpers import GOLDEN_DIR
+    d = np.load(os.path.join(GOLDEN_DIR, "matmul_known.npz"))
+    for rhs, out in (("rhs_vec", "out_vec"), ("rhs_mat", "out_mat")):
+        a = torch.tensor(d["lhs"], device="cuda")
+        x = torch.tensor(d[rhs], device="cuda")
+        assert np.allclose(ctx.matmul(a, x).cpu().numpy(), d[out], atol=1e-6)
+
+
+def test_matmul_exact_integer_layout_check(ctx, torch):
+    """Asymmetric exact-integer operands: any wrong MFMA lane map, swizzle or transposed C-write shows
+    as an exact mismatch (cdna guide: 'always A=I-check with ASYMMETRIC B')."""
+    for dt in (torch.float32, torch.float64):
+        m, n, l = 192, 128, 48
+        a = (torch.arange(m * n, device="cuda").reshape(m, n) % 7 - 3).to(dt)
+        x = (torch.arange(n * l, device="cuda").reshape(n, l) % 5 - 2).to(dt) + torch.arange(l, device="cuda").to(dt)
+        assert torch.equal(ctx.matmul(a, x), a @ x)
+        y = (torch.arange(m * l, device="cuda").reshape(m, l) % 11 - 5).to(dt)
+        assert torch.equal(ctx.matmul(a, y, trans=True), a.t() @ y)
+        ac = a.t().contiguous().t()
+        assert torch.equal(ctx.matmul(ac, x), a @ x)
+        assert torch.equal(ctx.matmul(ac, y, trans=True), a.t() @ y)
+
+
+# ---- random_mat_normal (mat_utils.rs:161-175) ---------------------------------------------------
+def test_fill_normal_matches_host_restatement(ctx, torch):
+    from tests.emu_harness import emu_fill_normal
+    for dt, npdt, tol in ((torch.float64, np.float64, 1e-12), (torch.float32, np.float32, 2e-5)):
+        t = torch.empty((96, 40), dtype=dt, device="cuda")
+        ctx.fill_normal(t, seed=20241008)
+        ref = emu_fill_normal(96, 40, seed=20241008, dtype=npdt)
+        assert np.max(np.abs(t.cpu().numpy() - ref)) < tol
+        shard = torch.empty((32, 40), dtype=dt, device="cuda")
+        ctx.fill_normal(shard, seed=20241008, row0=64, global_cols=40)
+        assert torch.equal(shard, t[64:96])
+        tc = torch.empty((40, 96), dtype=dt, device="cuda").t()  # column-major storage, same logical matrix
+        ctx.fill_normal(tc, seed=20241008)
+        assert torch.equal(tc, t)
+    big = torch.empty((2048, 1024), dtype=torch.float32, device="cuda")
+    ctx.fill_normal(big, seed=3)
+    assert abs(big.mean().item()) < 3e-3 and abs(big.std().item() - 1) < 3e-3
+
+
+# ---- random_svd vs the oracle on the golden fixtures ---------------------------------------------
+def _parity(ctx, a, k, q, p, omega, dtype, s_rtol, rec_rtol, device_path=False):
+    a = np.asarray(a, dtype=dtype)
+    om = np.asarray(omega, dtype=dtype)
+    if device_path:
+        import torch
+        u, s, vt = ctx.rsvd(torch.tensor(a, device="cuda"), k, q, p, omega=om)
+        u, s, vt = u.cpu().numpy(), s.cpu().numpy(), vt.cpu().numpy()
+    else:
+        u, s, vt = ctx.rsvd(a, k, q, p, omega=om)
+    assert u.dtype == dtype
+    uo, so, vto = orc.random_svd(a, k, q, p, omega=om)
+    check_factorization(a, u, s, vt, k, 0)
+    s1 = max(float(so[0, 0]), 1e-300)
+    assert np.max(np.abs(s.ravel().astype(np.float64) - so.ravel())) <= s_rtol * s1
+    # north star: ||A - U S Vt||_F / ||A||_F within 1e-5 of the CPU reference (same A, same Omega)
+    assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-5
+    rec = (u.astype(np.float64) * s.ravel()) @ vt.astype(np.float64)
+    reco = (uo.astype(np.float64) * so.ravel()) @ vto.astype(np.float64)
+    assert np.linalg.norm(rec - reco) <= rec_rtol * max(np.linalg.norm(reco), 1e-300)
+    nnz = int(np.sum(so.ravel() > 1e-5 * s1))
+    eps = np.finfo(dtype).eps
+    assert orth_err(u[:, :nnz]) <= 200 * eps * np.sqrt(a.shape[0])
+    assert orth_err(vt[:nnz, :].T) <= 200 * eps * np.sqrt(a.shape[1])
+    return u, s, vt
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rsvd_golden(ctx, name, dtype):
+    g = load_golden(name)
+    f64 = dtype == np.float64
+    tight = name not in ("lowrank256x96", "fat20x500_pod", "rankdef96x40")
+    s_rtol = (1e-10 if f64 else 2e-5) if tight else (1e-7 if f64 else 2e-3)
+    rec_rtol = (1e-8 if f64 else 1e-3) if tight else (1e-6 if f64 else 2e-2)
+    u, s, vt = _parity(ctx, g["A"], g["k"], g["q"], g["p"], g["omega"], dtype, s_rtol, rec_rtol)
+    if "ref_s" in g and f64:
+        # reference author's numpy rsvd, same Omega (examples/benchmark_rsvd.py:26-54)
+        assert np.max(np.abs(s.ravel() - g["ref_s"])) <= 1e-9 * g["ref_s"][0]
+    if name.startswith("known5x5"):
+        assert np.allclose(s.ravel(), orc.KNOWN_ANSWER_S[: g["k"]], atol=1e-3)  # random_svd.rs:170-195
+
+
+@pytest.mark.parametrize("order", ["C", "F", "strided", "device_C", "device_F", "device_strided"])
+@pytest.mark.parametrize("shape", [(70, 33), (33, 70), (64, 64), (1, 9), (9, 1), (301, 129)])
+def test_rsvd_layouts_and_shapes(ctx, torch, order, shape):
+    rng = np.random.default_rng(7)
+    m, n = shape
+    base = rng.standard_normal((2 * m, 2 * n))
+    k = max(1, min(m, n) // 3)
+    q, p = 2, 4
+    nt = min(m, n)
+    l = min(k + p, nt)
+    omega = rng.standard_normal((nt, l))
+    if order.startswith("device"):
+        tb = torch.tensor(base, device="cuda")
+        if order == "device_C":
+            a = tb[:m, :n].contiguous()
+        elif order == "device_F":
+            a = tb[:m, :n].t().contiguous().t()
+        else:
+            a = tb[::2, ::2]
+        u, s, vt = ctx.rsvd(a, k, q, p, omega=omega)
+        a_np = a.cpu().numpy()
+        u, s, vt = u.cpu().numpy(), s.cpu().numpy(), vt.cpu().numpy()
+    else:
+        a = {"C": np.ascontiguousarray(base[:m, :n]), "F": np.asfortranarray(base[:m, :n]), "strided": base[::2, ::2]}[order]
+        u, s, vt = ctx.rsvd(a, k, q, p, omega=omega)
+        a_np = np.array(a)
+    uo, so, vto = orc.random_svd(a_np, k, q, p, omega=omega)
+    assert s.shape == (k, 1) and u.shape == (m, k) and vt.shape == (k, n)
+    assert np.allclose(s, so, rtol=0, atol=1e-9 * so[0, 0])
+    assert abs(orc.relerr(a_np, u, s, vt) - orc.relerr(a_np, uo, so, vto)) < 1e-9
+
+
+def test_rsvd_shape_contract_10000x100(ctx):
+    # random_svd.rs:119-151 (test_rsvd_shape): 10000 x 100 f64, k=4, q=12, p=10; device RNG for Omega
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((10000, 100))
+    u, s, vt = ctx.rsvd(a, 4, 12, 10, seed=99)
+    rec = (u * s.ravel()) @ vt
+    assert rec.shape == a.shape
+    ex = np.linalg.svd(a, compute_uv=False)[:4]
+    assert np.all(s.ravel() <= ex * (1 + 1e-9)) and np.all(s.ravel() >= 0.9 * ex)
+    assert orth_err(u) < 1e-12 and orth_err(vt.T) < 1e-12
+    u2, s2, vt2 = ctx.rsvd(a, 4, 12, 10, seed=99)
+    assert np.array_equal(s, s2) and np.array_equal(u, u2)  # deterministic for a fixed seed
+
+
+def test_invalid_arguments_raise(ctx):
+    a = np.ones((6, 4))
+    with pytest.raises(ValueError):
+        ctx.rsvd(a, 5, 1, 2)   # rank > min(m, n): the reference panics (random_svd.rs:98-107)
+    with pytest.raises(ValueError):
+        ctx.rsvd(a, 0, 1, 2)
+    with pytest.raises(ValueError):
+        ctx.rsvd(a, 2, -1, 2)
+    with pytest.raises(ValueError):
+        ctx.rsvd(np.ones((3,)), 1, 1, 1)
+
+
+def test_power_iter_surface(ctx):
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((500, 60))
+    om = rng.standard_normal((60, 14))
+    for q in (0, 2, 5):
+        qe = ctx.power_iter(a, 14, q, omega=om)
+        qo = orc.power_iter(a, om, q)
+        assert qe.shape == (500, 14) and orth_err(qe) < 1e-12
+        assert np.linalg.norm(qe @ qe.T - qo @ qo.T) < 1e-8
+
+
+def test_drop_in_module_name(ctx):
+    # examples/benchmark_rsvd.py:13,101 : import corrla_rs as hrl; hrl.rsvd(test_A, 4, 8, 10)
+    import corrla_rs as hrl
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((400, 90))
+    u, s, vt = hrl.rsvd(a, 4, 8, 10)
+    assert u.shape == (400, 4) and s.shape == (4, 1) and vt.shape == (4, 90) and u.dtype == np.float64
+    ex = np.linalg.svd(a, compute_uv=False)[:4]
+    assert np.allclose(s.ravel(), ex, rtol=2e-2)
+
+
+# ---- BASELINE.json configs at full size: size-independent properties ----------------------------
+def _device_checks(torch, a, u, s, vt, k, dtype_eps):
+    """Orthonormality, Rayleigh consistency (s_i = u_i^T A v_i), optimality bound and relerr identity."""
+    ud, vd, sd = u.double(), vt.double().t(), s.double().ravel()
+    eye = torch.eye(k, dtype=torch.float64, device=a.device)
+    assert (ud.t() @ ud - eye).abs().max().item() < 50 * dtype_eps * np.sqrt(k) * 4
+    assert (vd.t() @ vd - eye).abs().max().item() < 50 * dtype_eps * np.sqrt(k) * 4
+    av = torch.empty((a.shape[0], k), dtype=torch.float64, device=a.device)
+    step = 2048
+    for r0 in range(0, a.shape[0], step):
+        av[r0:r0 + step] = a[r0:r0 + step].double() @ vd
+    ray = (ud * av).sum(dim=0)
+    assert ((ray - sd).abs().max() / sd[0]).item() < 1e3 * dtype_eps
+    assert torch.all(sd[:-1] >= sd[1:] - 1e-6 * sd[0]) and torch.all(sd >= 0)
+    fro2 = float(sum((a[r0:r0 + step].double() ** 2).sum().item() for r0 in range(0, a.shape[0], step)))
+    # ||A - U S Vt||^2 = ||A||^2 - 2 sum s_i ray_i + sum s_i^2 for orthonormal U, V
+    err2 = fro2 - 2 * float((sd * ray).sum().item()) + float((sd ** 2).sum().item())
+    return np.sqrt(max(err2, 0.0) / fro2)
+
+
+def test_c2_full_size_f32_properties(ctx, torch):
+    """BASELINE config 2: 16384 x 16384 f32, rank 128, 2 power iterations, p=10."""
+    m = n = 16384
+    k, q, p = 128, 2, 10
+    a = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    ctx.fill_normal(a, seed=20241008)
+    u, s, vt = ctx.rsvd(a, k, q, p, seed=1)
+    re = _device_checks(torch, a, u, s, vt, k, 1.2e-7)
+    # Gaussian square matrix: sigma_1 ~ 2 sqrt(n); rank-128 relerr a little under 1
+    assert 0.9 < re < 0.999
+    assert 1.7 * np.sqrt(n) < s[0, 0].item() < 2.1 * np.sqrt(n)
+    # linearity (size-independent): rsvd(2A) has 2x the singular values, same seed
+    u2, s2, vt2 = ctx.rsvd(a * 2, k, q, p, seed=1)
+    assert torch.allclose(s2, 2 * s, rtol=1e-5)
+    # sampled parity of the sketch GEMM against f64 on random rows
+    om = torch.empty((n, 138), dtype=torch.float32, device="cuda")
+    ctx.fill_normal(om, seed=5)
+    y = ctx.matmul(a, om)
+    rows = torch.randint(0, m, (64,), device="cuda")
+    ref = a[rows].double() @ om.double()
+    assert ((y[rows].double() - ref).abs().max() / ref.abs().max()).item() < 2e-5
+
+
+def test_c3_like_f64_properties(ctx, torch):
+    """BASELINE config 3 shape family (tall f64 snapshot matrix, wide sketch l = 266 > one column
+    block) at 1/4 of the rows so the CPU side stays small: 16384 x 4096 f64, rank 256, POD defaults."""
+    m, n, k, q, p = 16384, 4096, 256, 2, 10
+    a = torch.empty((m, n), dtype=torch.float64, device="cuda")
+    ctx.fill_normal(a, seed=7)
+    u, s, vt = ctx.rsvd(a, k, q, p, seed=2)
+    re = _device_checks(torch, a, u, s, vt, k, 2.2e-16)
+    assert 0.8 < re < 0.999
+
+
+def test_c4_like_tall_f32(ctx, torch):
+    """BASELINE config 4 shape family: very tall, n = 512, rank 64 (one GPU's 1/8 shard: 1.25M rows)."""
+    m, n, k, q, p = 1_250_000, 512, 64, 2, 10
+    a = torch.empty((m, n), dtype=torch.float32, device="cuda")
+    ctx.fill_normal(a, seed=11)
+    u, s, vt = ctx.rsvd(a, k, q, p, seed=3)
+    re = _device_checks(torch, a, u, s, vt, k, 1.2e-7)
+    assert 0.8 < re < 0.999
