@@ -70,7 +70,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m corrla_rs_amd.build` (hipcc, gfx950). "
             "corrla_rs_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
         fn.restype = res

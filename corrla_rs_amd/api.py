@@ -12,8 +12,11 @@ CUDA tensors take the device-pointer entry points and return torch tensors on th
 float32 input runs the f32 path (the pyo3 surface is f64-only; anything that is not f32 is
 converted to f64, as PyReadonlyArray2<f64> extraction would require).
 """
+import atexit
 import ctypes as C
+import sys
 import threading
+import weakref
 
 import numpy as np
 
@@ -26,6 +29,22 @@ def _is_torch(x):
     return type(x).__module__.split(".")[0] == "torch"
 
 
+# Contexts own HIP streams / allocations / RCCL communicators: destroy them before the interpreter (and
+# the HIP runtime's own static destructors) tear down, never from a late __del__.
+_live = weakref.WeakSet()
+
+
+def _close_all():
+    for c in list(_live):
+        try:
+            c.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
+
+
 class Context:
     """One device, one stream, one workspace arena (corrla_ctx).  Not thread-parallel: calls on one
     context serialise, as calls on one faer global thread pool do in the reference."""
@@ -36,13 +55,16 @@ class Context:
         L.check(self._lib.corrla_ctx_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        _live.add(self)
 
     def close(self):
-        if getattr(self, "_h", None):
-            self._lib.corrla_ctx_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.corrla_ctx_destroy(h)
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return  # too late to touch the HIP runtime; atexit already closed live contexts
         try:
             self.close()
         except Exception:

@@ -40,7 +40,7 @@ def build_product(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libcorrla_rsvd.so")
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
            "-I" + os.path.join(ROOT, "include"), os.path.join(CSRC, "corrla_rsvd.hip"),
            "-o", LIB_PATH, "-L" + os.path.join(ROCM, "lib"), "-lrccl",
            "-Wl,-rpath," + os.path.join(ROCM, "lib")]
@@ -56,7 +56,7 @@ def build_emu(force=False, verbose=False):
                                              os.path.join(ROOT, "include", "corrla_rsvd.h")]
     if not force and _newer(EMU_PATH, srcs):
         return EMU_PATH
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
            os.path.join(EMU_DIR, "emu_backend.cpp"), "-o", EMU_PATH]
     if verbose:
         print(" ".join(cmd))

@@ -88,9 +88,9 @@ corrla_status time_sketch_c(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, i
 
 extern "C" {
 
-const char* corrla_version(void) { return "corrla_rsvd 0.1.0 gfx950"; }
-const char* corrla_last_error(void) { return last_error_slot().c_str(); }
-int corrla_device_count(void) {
+CORRLA_API const char* corrla_version(void) { return "corrla_rsvd 0.1.0 gfx950"; }
+CORRLA_API const char* corrla_last_error(void) { return last_error_slot().c_str(); }
+CORRLA_API int corrla_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
     (void)hipGetLastError();
@@ -99,18 +99,18 @@ int corrla_device_count(void) {
   return n;
 }
 
-corrla_status corrla_ctx_create(int device_ordinal, corrla_ctx** out) {
+CORRLA_API corrla_status corrla_ctx_create(int device_ordinal, corrla_ctx** out) {
   return guarded([&] {
     if (!out) throw Error(ST_EINVAL, "out is NULL");
     *out = nullptr;
     *out = new corrla_ctx(device_ordinal);
   });
 }
-void corrla_ctx_destroy(corrla_ctx* ctx) { delete ctx; }
-corrla_status corrla_ctx_synchronize(corrla_ctx* ctx) {
+CORRLA_API void corrla_ctx_destroy(corrla_ctx* ctx) { delete ctx; }
+CORRLA_API corrla_status corrla_ctx_synchronize(corrla_ctx* ctx) {
   return guarded([&] { need(ctx)->dev.sync(); });
 }
-corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out) {
+CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);
     if (!out) throw Error(ST_EINVAL, "out is NULL");
@@ -128,40 +128,40 @@ corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out) {
 }
 
 #define CORRLA_DEFINE(SUF, T)                                                                                          \
-  corrla_status corrla_rsvd_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,           \
+  CORRLA_API corrla_status corrla_rsvd_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,           \
                                   int64_t rank, int64_t n_iter, int64_t p, const corrla_opts* o, T* u, int64_t ldu,    \
                                   T* s, T* vt, int64_t ldvt) {                                                         \
     return rsvd_c<T>(ctx, true, false, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt);                      \
   }                                                                                                                    \
-  corrla_status corrla_rsvd_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,       \
+  CORRLA_API corrla_status corrla_rsvd_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,       \
                                       int64_t rank, int64_t n_iter, int64_t p, const corrla_opts* o, T* u,             \
                                       int64_t ldu, T* s, T* vt, int64_t ldvt) {                                        \
     return rsvd_c<T>(ctx, false, false, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt);                     \
   }                                                                                                                    \
-  corrla_status corrla_rsvd_sharded_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs,           \
+  CORRLA_API corrla_status corrla_rsvd_sharded_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs,           \
                                               int64_t cs, int64_t rank, int64_t n_iter, int64_t p,                     \
                                               const corrla_opts* o, T* u, int64_t ldu, T* s, T* vt, int64_t ldvt) {    \
     return rsvd_c<T>(ctx, false, true, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt);                      \
   }                                                                                                                    \
-  corrla_status corrla_power_iter_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,     \
+  CORRLA_API corrla_status corrla_power_iter_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,     \
                                         int64_t width, int64_t n_iter, const corrla_opts* o, T* q, int64_t ldq) {      \
     return power_c<T>(ctx, true, a, m, n, rs, cs, width, n_iter, o, q, ldq);                                           \
   }                                                                                                                    \
-  corrla_status corrla_power_iter_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs,             \
+  CORRLA_API corrla_status corrla_power_iter_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs,             \
                                             int64_t cs, int64_t width, int64_t n_iter, const corrla_opts* o, T* q,     \
                                             int64_t ldq) {                                                             \
     return power_c<T>(ctx, false, a, m, n, rs, cs, width, n_iter, o, q, ldq);                                          \
   }                                                                                                                    \
-  corrla_status corrla_matmul_dev_##SUF(corrla_ctx* ctx, int trans, const T* a, int64_t m, int64_t n, int64_t rs,      \
+  CORRLA_API corrla_status corrla_matmul_dev_##SUF(corrla_ctx* ctx, int trans, const T* a, int64_t m, int64_t n, int64_t rs,      \
                                         int64_t cs, const T* x, int64_t ldx, int64_t l, T beta, T* res,                \
                                         int64_t ldres) {                                                               \
     return matmul_c<T>(ctx, trans, a, m, n, rs, cs, x, ldx, l, beta, res, ldres);                                      \
   }                                                                                                                    \
-  corrla_status corrla_fill_normal_dev_##SUF(corrla_ctx* ctx, T* p, int64_t rows, int64_t cols, int64_t rs,            \
+  CORRLA_API corrla_status corrla_fill_normal_dev_##SUF(corrla_ctx* ctx, T* p, int64_t rows, int64_t cols, int64_t rs,            \
                                              int64_t cs, uint64_t seed, int64_t row0, int64_t global_cols) {           \
     return fill_c<T>(ctx, p, rows, cols, rs, cs, seed, row0, global_cols);                                             \
   }                                                                                                                    \
-  corrla_status corrla_time_sketch_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs,            \
+  CORRLA_API corrla_status corrla_time_sketch_dev_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs,            \
                                              int64_t cs, const T* x, int64_t ldx, int64_t l, T* y, int64_t ldy,        \
                                              int reps, double* avg_ms) {                                               \
     return time_sketch_c<T>(ctx, a, m, n, rs, cs, x, ldx, l, y, ldy, reps, avg_ms);                                    \
@@ -170,7 +170,7 @@ corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out) {
 CORRLA_DEFINE(f32, float)
 CORRLA_DEFINE(f64, double)
 
-corrla_status corrla_comm_unique_id(void* out128) {
+CORRLA_API corrla_status corrla_comm_unique_id(void* out128) {
   return guarded([&] {
     if (!out128) throw Error(ST_EINVAL, "out128 is NULL");
     ncclUniqueId id;
@@ -179,7 +179,7 @@ corrla_status corrla_comm_unique_id(void* out128) {
     std::memcpy(out128, &id, sizeof(id));
   });
 }
-corrla_status corrla_ctx_comm_init(corrla_ctx* ctx, const void* unique_id128, int rank, int nranks) {
+CORRLA_API corrla_status corrla_ctx_comm_init(corrla_ctx* ctx, const void* unique_id128, int rank, int nranks) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);
     if (!unique_id128 || nranks < 1 || rank < 0 || rank >= nranks) throw Error(ST_EINVAL, "bad communicator arguments");

@@ -32,6 +32,13 @@
 extern "C" {
 #endif
 
+/* Only the C ABI below is exported; every C++ symbol of the library has hidden visibility. */
+#if defined(__GNUC__)
+#define CORRLA_API __attribute__((visibility("default")))
+#else
+#define CORRLA_API
+#endif
+
 typedef struct corrla_ctx corrla_ctx;
 
 typedef enum corrla_status {
@@ -81,19 +88,19 @@ typedef struct corrla_timings {
 /* ---- library / context ------------------------------------------------------------- */
 
 /* "corrla_rsvd <version> gfx950" */
-const char* corrla_version(void);
+CORRLA_API const char* corrla_version(void);
 /* thread-local message of the last failing call on this thread */
-const char* corrla_last_error(void);
+CORRLA_API const char* corrla_last_error(void);
 /* number of visible HIP devices (0 when none / no driver) */
-int corrla_device_count(void);
+CORRLA_API int corrla_device_count(void);
 
 /* One context = one device, one stream, one workspace arena (and optionally one RCCL
  * communicator).  Replaces faer's process-global Parallelism (mat_utils.rs:31,
  * random_svd.rs:122).  Calls on one context serialise. */
-corrla_status corrla_ctx_create(int device_ordinal, corrla_ctx** out);
-void corrla_ctx_destroy(corrla_ctx* ctx);
-corrla_status corrla_ctx_synchronize(corrla_ctx* ctx);
-corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out);
+CORRLA_API corrla_status corrla_ctx_create(int device_ordinal, corrla_ctx** out);
+CORRLA_API void corrla_ctx_destroy(corrla_ctx* ctx);
+CORRLA_API corrla_status corrla_ctx_synchronize(corrla_ctx* ctx);
+CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out);
 
 /* ---- the hot path: random_svd -------------------------------------------------------
  * Replaces  pub fn random_svd<T>(a_mat: MatRef<T>, omega_rank, n_iter, n_oversamples)
@@ -101,17 +108,17 @@ corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out);
  * and, through it, the pyo3 surface corrla_rs.rsvd(a, n_rank, n_iters, n_oversamples)
  *                                                              src/lib_math_utils_py.rs:21-36
  * Host-pointer variants (A, U, S, Vt, opts->omega in host memory). */
-corrla_status corrla_rsvd_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
+CORRLA_API corrla_status corrla_rsvd_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
                               int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
                               const corrla_opts* opts, float* u, int64_t ldu, float* s, float* vt, int64_t ldvt);
-corrla_status corrla_rsvd_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
+CORRLA_API corrla_status corrla_rsvd_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
                               int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
                               const corrla_opts* opts, double* u, int64_t ldu, double* s, double* vt, int64_t ldvt);
 /* Device-pointer variants: A, U, S, Vt are HIP device pointers on the context's device. */
-corrla_status corrla_rsvd_dev_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
+CORRLA_API corrla_status corrla_rsvd_dev_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
                                   int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
                                   const corrla_opts* opts, float* u, int64_t ldu, float* s, float* vt, int64_t ldvt);
-corrla_status corrla_rsvd_dev_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
+CORRLA_API corrla_status corrla_rsvd_dev_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
                                   int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
                                   const corrla_opts* opts, double* u, int64_t ldu, double* s, double* vt, int64_t ldvt);
 
@@ -121,16 +128,16 @@ corrla_status corrla_rsvd_dev_f64(corrla_ctx* ctx, const double* a, int64_t m, i
  * `width` is the ALREADY OVERSAMPLED sketch width (the reference's `omega_rank` argument of
  * power_iter), width <= n.  Q: column-major m x width, leading dimension ldq.  Requires m >= 1,
  * n >= 1 (no fat->tall transpose here, exactly as in the reference). */
-corrla_status corrla_power_iter_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
+CORRLA_API corrla_status corrla_power_iter_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
                                     int64_t col_stride, int64_t width, int64_t n_iter, const corrla_opts* opts,
                                     float* q, int64_t ldq);
-corrla_status corrla_power_iter_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
+CORRLA_API corrla_status corrla_power_iter_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
                                     int64_t col_stride, int64_t width, int64_t n_iter, const corrla_opts* opts,
                                     double* q, int64_t ldq);
-corrla_status corrla_power_iter_dev_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
+CORRLA_API corrla_status corrla_power_iter_dev_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
                                         int64_t col_stride, int64_t width, int64_t n_iter, const corrla_opts* opts,
                                         float* q, int64_t ldq);
-corrla_status corrla_power_iter_dev_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
+CORRLA_API corrla_status corrla_power_iter_dev_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
                                         int64_t col_stride, int64_t width, int64_t n_iter, const corrla_opts* opts,
                                         double* q, int64_t ldq);
 
@@ -142,10 +149,10 @@ corrla_status corrla_power_iter_dev_f64(corrla_ctx* ctx, const double* a, int64_
  *   trans == 0 : res (m x l) = beta * A   * X (n x l)
  *   trans == 1 : res (n x l) = beta * A^T * X (m x l)
  * X and res are column-major with leading dimensions ldx / ldres.  DEVICE pointers. */
-corrla_status corrla_matmul_dev_f32(corrla_ctx* ctx, int trans, const float* a, int64_t m, int64_t n,
+CORRLA_API corrla_status corrla_matmul_dev_f32(corrla_ctx* ctx, int trans, const float* a, int64_t m, int64_t n,
                                     int64_t row_stride, int64_t col_stride, const float* x, int64_t ldx, int64_t l,
                                     float beta, float* res, int64_t ldres);
-corrla_status corrla_matmul_dev_f64(corrla_ctx* ctx, int trans, const double* a, int64_t m, int64_t n,
+CORRLA_API corrla_status corrla_matmul_dev_f64(corrla_ctx* ctx, int trans, const double* a, int64_t m, int64_t n,
                                     int64_t row_stride, int64_t col_stride, const double* x, int64_t ldx, int64_t l,
                                     double beta, double* res, int64_t ldres);
 
@@ -154,9 +161,9 @@ corrla_status corrla_matmul_dev_f64(corrla_ctx* ctx, int trans, const double* a,
  * Fills a DEVICE matrix with i.i.d. N(0,1) from a counter-based Philox4x32-10 + Box-Muller
  * stream: element (i, j) of the logical matrix depends only on (seed, (row0 + i) * global_cols + j),
  * so any row shard generates its own rows bit-identically.  Storage strides in elements. */
-corrla_status corrla_fill_normal_dev_f32(corrla_ctx* ctx, float* p, int64_t rows, int64_t cols, int64_t row_stride,
+CORRLA_API corrla_status corrla_fill_normal_dev_f32(corrla_ctx* ctx, float* p, int64_t rows, int64_t cols, int64_t row_stride,
                                          int64_t col_stride, uint64_t seed, int64_t row0, int64_t global_cols);
-corrla_status corrla_fill_normal_dev_f64(corrla_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t row_stride,
+CORRLA_API corrla_status corrla_fill_normal_dev_f64(corrla_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t row_stride,
                                          int64_t col_stride, uint64_t seed, int64_t row0, int64_t global_cols);
 
 /* ---- measurement hook ---------------------------------------------------------------
@@ -164,10 +171,10 @@ corrla_status corrla_fill_normal_dev_f64(corrla_ctx* ctx, double* p, int64_t row
  * hipEvents recorded on the context's stream (the stream the kernel runs on) and returns the
  * average kernel-sequence duration in milliseconds.  DEVICE pointers, layouts as in
  * corrla_matmul_dev_*.  Used by bench.py for roofline.achieved. */
-corrla_status corrla_time_sketch_dev_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
+CORRLA_API corrla_status corrla_time_sketch_dev_f32(corrla_ctx* ctx, const float* a, int64_t m, int64_t n, int64_t row_stride,
                                          int64_t col_stride, const float* x, int64_t ldx, int64_t l, float* y,
                                          int64_t ldy, int reps, double* avg_ms);
-corrla_status corrla_time_sketch_dev_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
+CORRLA_API corrla_status corrla_time_sketch_dev_f64(corrla_ctx* ctx, const double* a, int64_t m, int64_t n, int64_t row_stride,
                                          int64_t col_stride, const double* x, int64_t ldx, int64_t l, double* y,
                                          int64_t ldy, int reps, double* avg_ms);
 
@@ -176,19 +183,19 @@ corrla_status corrla_time_sketch_dev_f64(corrla_ctx* ctx, const double* a, int64
  * host program (torch.distributed / MPI / a file), then every rank calls corrla_ctx_comm_init.
  * The communicator is RCCL; collectives are enqueued on the context's stream. */
 #define CORRLA_UNIQUE_ID_BYTES 128
-corrla_status corrla_comm_unique_id(void* out128);
-corrla_status corrla_ctx_comm_init(corrla_ctx* ctx, const void* unique_id128, int rank, int nranks);
+CORRLA_API corrla_status corrla_comm_unique_id(void* out128);
+CORRLA_API corrla_status corrla_ctx_comm_init(corrla_ctx* ctx, const void* unique_id128, int rank, int nranks);
 
 /* Row-sharded random_svd: this rank holds rows [row0, row0 + m_local) of the TALL matrix
  * A (m_global x n, m_global >= n), unit column stride or unit row stride as above.
  * U_local: m_local x k (this rank's rows of U); S and Vt are replicated on every rank.
  * Exchanges per call: q+1 all-reduces of n x l (Z and B^T), the l x l Gram all-reduces of the
  * orthonormalisations, one scalar per power iteration.  DEVICE pointers. */
-corrla_status corrla_rsvd_sharded_dev_f32(corrla_ctx* ctx, const float* a_local, int64_t m_local, int64_t n,
+CORRLA_API corrla_status corrla_rsvd_sharded_dev_f32(corrla_ctx* ctx, const float* a_local, int64_t m_local, int64_t n,
                                           int64_t row_stride, int64_t col_stride, int64_t rank, int64_t n_iter,
                                           int64_t n_oversamples, const corrla_opts* opts, float* u_local, int64_t ldu,
                                           float* s, float* vt, int64_t ldvt);
-corrla_status corrla_rsvd_sharded_dev_f64(corrla_ctx* ctx, const double* a_local, int64_t m_local, int64_t n,
+CORRLA_API corrla_status corrla_rsvd_sharded_dev_f64(corrla_ctx* ctx, const double* a_local, int64_t m_local, int64_t n,
                                           int64_t row_stride, int64_t col_stride, int64_t rank, int64_t n_iter,
                                           int64_t n_oversamples, const corrla_opts* opts, double* u_local, int64_t ldu,
                                           double* s, double* vt, int64_t ldvt);

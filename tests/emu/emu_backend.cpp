@@ -195,14 +195,15 @@ class EmuDev {
   }
 };
 
+#define EMU_API __attribute__((visibility("default")))
 extern "C" {
-const char* corrla_emu_last_error(void) { return last_error_slot().c_str(); }
-void corrla_emu_set_comm(emu_allreduce_fn fn, int nranks) {
+EMU_API const char* corrla_emu_last_error(void) { return last_error_slot().c_str(); }
+EMU_API void corrla_emu_set_comm(emu_allreduce_fn fn, int nranks) {
   g_allreduce = fn;
   g_nranks = nranks;
 }
 #define EMU_DEFINE(SUF, T)                                                                                             \
-  int corrla_emu_rsvd_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank, int64_t n_iter,    \
+  EMU_API int corrla_emu_rsvd_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank, int64_t n_iter,    \
                             int64_t p, const corrla_opts* o, T* u, int64_t ldu, T* s, T* vt, int64_t ldvt,             \
                             int* qr_passes) {                                                                          \
     return guarded([&] {                                                                                               \
@@ -212,7 +213,7 @@ void corrla_emu_set_comm(emu_allreduce_fn fn, int nranks) {
       if (qr_passes) *qr_passes = tm.qr_passes;                                                                        \
     });                                                                                                                \
   }                                                                                                                    \
-  int corrla_emu_rsvd_sharded_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank,            \
+  EMU_API int corrla_emu_rsvd_sharded_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank,            \
                                     int64_t n_iter, int64_t p, const corrla_opts* o, T* u, int64_t ldu, T* s, T* vt,   \
                                     int64_t ldvt) {                                                                    \
     return guarded([&] {                                                                                               \
@@ -221,21 +222,21 @@ void corrla_emu_set_comm(emu_allreduce_fn fn, int nranks) {
                             false);                                                                                    \
     });                                                                                                                \
   }                                                                                                                    \
-  int corrla_emu_power_iter_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t width,             \
+  EMU_API int corrla_emu_power_iter_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t width,             \
                                   int64_t n_iter, const corrla_opts* o, T* q, int64_t ldq) {                           \
     return guarded([&] {                                                                                               \
       EmuDev dev;                                                                                                      \
       power_iter_entry<EmuDev, T>(dev, true, a, m, n, rs, cs, width, n_iter, o, q, ldq);                               \
     });                                                                                                                \
   }                                                                                                                    \
-  int corrla_emu_matmul_##SUF(int trans, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, const T* x,         \
+  EMU_API int corrla_emu_matmul_##SUF(int trans, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, const T* x,         \
                               int64_t ldx, int64_t l, T beta, T* res, int64_t ldres) {                                 \
     return guarded([&] {                                                                                               \
       EmuDev dev;                                                                                                      \
       matmul_entry<EmuDev, T>(dev, trans, a, m, n, rs, cs, x, ldx, l, beta, res, ldres);                               \
     });                                                                                                                \
   }                                                                                                                    \
-  int corrla_emu_fill_normal_##SUF(T* p, int64_t rows, int64_t cols, int64_t rs, int64_t cs, uint64_t seed,            \
+  EMU_API int corrla_emu_fill_normal_##SUF(T* p, int64_t rows, int64_t cols, int64_t rs, int64_t cs, uint64_t seed,            \
                                    int64_t row0, int64_t gcols) {                                                      \
     return guarded([&] {                                                                                               \
       EmuDev dev;                                                                                                      \
@@ -246,11 +247,11 @@ EMU_DEFINE(f32, float)
 EMU_DEFINE(f64, double)
 
 // direct hooks for the host-side small dense routines (product code in small_linalg.hpp)
-int corrla_emu_chol_upper(int n, double* g, int ld, double piv_rel, double* min_ratio) {
+EMU_API int corrla_emu_chol_upper(int n, double* g, int ld, double piv_rel, double* min_ratio) {
   return small::chol_upper(n, g, ld, piv_rel, min_ratio) ? 1 : 0;
 }
-void corrla_emu_triu_inverse(int n, double* r, int ld) { small::triu_inverse(n, r, ld); }
-int corrla_emu_jacobi_svd(int n, const double* c, int ld, double* u, double* s, double* v, double tol) {
+EMU_API void corrla_emu_triu_inverse(int n, double* r, int ld) { small::triu_inverse(n, r, ld); }
+EMU_API int corrla_emu_jacobi_svd(int n, const double* c, int ld, double* u, double* s, double* v, double tol) {
   return small::jacobi_svd(n, c, ld, u, s, v, tol);
 }
 }
