@@ -70,7 +70,15 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m corrla_rs_amd.build` (hipcc, gfx950). "
             "corrla_rs_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    # torch wheels bundle their own ROCm runtime (libamdhip64 / libhsa-runtime64 / librccl, same SONAMEs as
+    # /opt/rocm).  One process must use ONE of them: when torch is installed, import it first so this
+    # library binds to the copies torch already loaded (device pointers and RCCL are then shared with
+    # torch.distributed); RTLD_GLOBAL keeps the reverse order working when torch is absent at load time.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
         fn.restype = res

@@ -146,8 +146,8 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
   RsvdDriver<Dev, T> drv(dev, profile);
   Skinny<T> ut = dev.template alloc_skinny<T>(ta.mt, k);
   Skinny<T> vtall = dev.template alloc_skinny<T>(ta.nt, k);
-  std::vector<double> sv;
-  drv.random_svd_tall(ta, k, l, n_iter, ro, ut, sv, vtall);
+  T* s_dev = dev.template alloc_scalar<T>((int)k);
+  drv.random_svd_tall(ta, k, l, n_iter, ro, ut, s_dev, vtall);
   // random_svd.rs:96-109: tall -> (U, S, V^T); fat -> (V, S, U^T) of the transposed problem
   if (!fat) {
     dev.copy_out(ut, k, u, ldu, /*transpose=*/false, host_ptrs);
@@ -156,9 +156,7 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
     dev.copy_out(vtall, k, u, ldu, false, host_ptrs);
     dev.copy_out(ut, k, vt, ldvt, true, host_ptrs);
   }
-  std::vector<T> st(k);
-  for (int64_t i = 0; i < k; ++i) st[i] = (T)sv[i];
-  dev.store_values(st.data(), k, s, host_ptrs);
+  dev.copy_values_out(s_dev, k, s, host_ptrs);
   dev.end_call();
   if (tm_out) *tm_out = drv.tm;
 }

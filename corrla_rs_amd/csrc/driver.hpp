@@ -273,9 +273,9 @@ struct RsvdDriver {
   }
 
   // ---- random_svd, random_svd.rs:63-110, on the already-tall view ------------------------
-  // u_tall: mt x k, v_tall: nt x k (both skinny, allocated by the caller), s: k values.
+  // u_tall: mt x k, v_tall: nt x k (both skinny, allocated by the caller), s_dev: k values (device).
   void random_svd_tall(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
-                       std::vector<double>& s, Skinny<T>& v_tall) {
+                       T* s_dev, Skinny<T>& v_tall) {
     PhaseTimer total;
     Skinny<T> q = dev.template alloc_skinny<T>(a.mt, l);
     Skinny<T> q2 = dev.template alloc_skinny<T>(a.mt, l);
@@ -295,20 +295,13 @@ struct RsvdDriver {
     phase(tm.qr_ms, pt);
     Skinny<T> cd = dev.template alloc_skinny<T>(l, l);
     dev.gemm_nn(as_rowmajor_transposed(qb, l), bt, cd, kNone);
-    std::vector<double> c((size_t)l * l), uc((size_t)l * l), vc((size_t)l * l), sv(l);
-    dev.download_skinny(cd, l, l, c.data());
-    const double eps = (double)std::numeric_limits<T>::epsilon();
-    if (small::jacobi_svd((int)l, c.data(), (int)l, uc.data(), sv.data(), vc.data(), std::max(1e-15, eps * 1e-3)) < 0)
-      throw Error(ST_ENUMERIC, "non-finite core matrix in small SVD");
-    s.assign(sv.begin(), sv.begin() + k);
+    Skinny<T> m1 = dev.template alloc_skinny<T>(l, k);  // U~[:, :k] = Vc[:, :k]
+    Skinny<T> m2 = dev.template alloc_skinny<T>(l, k);  // Uc[:, :k]
+    dev.small_svd(cd, l, k, m1, m2, s_dev);
     phase(tm.small_svd_ms, pt);
     // U = Q * U~[:, :k]                                                               :92, :96-109
-    Skinny<T> m1 = dev.template alloc_skinny<T>(l, k);
-    dev.upload_skinny(vc.data(), l, k, l, m1);
     dev.gemm_tn(as_rowmajor_transposed(q, l), m1, u_tall, kNone);
     // V = Qb * Uc[:, :k]
-    Skinny<T> m2 = dev.template alloc_skinny<T>(l, k);
-    dev.upload_skinny(uc.data(), l, k, l, m2);
     dev.gemm_tn(as_rowmajor_transposed(qb, l), m2, v_tall, kNone);
     phase(tm.finalize_ms, pt);
     tm.total_ms += total.lap();
@@ -319,6 +312,22 @@ struct RsvdDriver {
     slot += pt.lap();
   }
 };
+
+// Host SVD of the l x l core (download, one-sided Jacobi in f64, upload the sorted factors): the
+// backend-independent fallback behind Dev::small_svd.  C = Uc S Vc^T;  m1 <- Vc[:, :k], m2 <- Uc[:, :k].
+template <class Dev, class T>
+inline void small_svd_host(Dev& dev, const Skinny<T>& cd, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev) {
+  std::vector<double> c((size_t)l * l), uc((size_t)l * l), vc((size_t)l * l), sv(l);
+  dev.download_skinny(cd, l, l, c.data());
+  const double eps = (double)std::numeric_limits<T>::epsilon();
+  if (small::jacobi_svd((int)l, c.data(), (int)l, uc.data(), sv.data(), vc.data(), std::max(1e-15, eps * 1e-3)) < 0)
+    throw Error(ST_ENUMERIC, "non-finite core matrix in small SVD");
+  dev.upload_skinny(vc.data(), l, k, l, m1);
+  dev.upload_skinny(uc.data(), l, k, l, m2);
+  std::vector<T> st(k);
+  for (int64_t i = 0; i < k; ++i) st[i] = (T)sv[i];
+  dev.store_values(st.data(), k, s_dev, /*dst_is_host=*/false);
+}
 
 // ---- argument handling shared by the C ABI of the product and of the test emulation --------
 struct Layout {

@@ -6,8 +6,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -69,6 +71,10 @@ class HipDev {
     CORRLA_HIP(hipMemsetAsync(zero_page_, 0, 256, stream));
     set_lds_attrs<float>();
     set_lds_attrs<double>();
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
     split_nn_override_ = env_int("CORRLA_SPLIT_NN", 0);
     split_tn_override_ = env_int("CORRLA_SPLIT_TN", 0);
   }
@@ -228,6 +234,28 @@ class HipDev {
       CORRLA_HIP(hipMemcpyAsync(dst, host_src, sizeof(T) * n, hipMemcpyHostToDevice, stream));
       sync();
     }
+  }
+  template <class T>
+  void copy_values_out(const T* src_dev, int64_t n, T* dst, bool dst_is_host) {
+    CORRLA_HIP(hipMemcpyAsync(dst, src_dev, sizeof(T) * n, dst_is_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                              stream));
+    if (dst_is_host) sync();
+  }
+  // SVD of the l x l core (random_svd.rs:89): device Jacobi when W fits in LDS, host Jacobi otherwise
+  template <class T>
+  void small_svd(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev) {
+    const size_t lds = k::jacobi_lds_bytes((int)l, sizeof(T));
+    if (lds > (size_t)160 * 1024 || env_int("CORRLA_HOST_SVD", 0)) {
+      small_svd_host(*this, c, l, k, m1, m2, s_dev);
+      return;
+    }
+    const int64_t ldv = round_up(l, 16);
+    T* vg = (T*)alloc_bytes((size_t)ldv * l * sizeof(T));
+    int* info = (int*)alloc_bytes(sizeof(int) * 4);
+    const T tol = (T)(std::sqrt((double)l) * (double)std::numeric_limits<T>::epsilon());
+    hipLaunchKernelGGL((k::jacobi_svd_kernel<T>), dim3(1), dim3(1024), lds, stream, (const T*)c.p, c.ld, (int)l, vg, ldv,
+                       m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, 40, info);
+    CORRLA_HIP(hipGetLastError());
   }
   // skinny (rows x ncols) -> column-major destination, optionally transposed (ncols x rows)
   template <class T>

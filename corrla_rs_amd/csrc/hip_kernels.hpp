@@ -389,6 +389,132 @@ __global__ void fill_normal_kernel(T* p, int64_t rows, int64_t cols, int64_t rs,
   }
 }
 
+// ---- SVD of the l x l core (random_svd.rs:89) on the device -------------------------------------
+// One-sided (Hestenes) Jacobi in ONE workgroup of 1024 threads: W = C lives in LDS (column-major,
+// odd pitch), the accumulated right rotations V live in global memory (L2-resident, same CU).  A
+// round-robin tournament gives n/2 disjoint column pairs per step; each pair is rotated by a 16-lane
+// group (64 pairs in flight), with the three dot products reduced by xor-shuffles inside the group.
+// On exit the columns of W are U_c * sigma and V = V_c with C = U_c diag(sigma) V_c^T.  The kernel
+// sorts sigma descending and writes sigma[:k], V_c[:, :k] (-> m1) and U_c[:, :k] (-> m2) directly into
+// the zero-padded skinny operands of the GEMMs that follow (U = Q * m1, V = Qb * m2), so the final
+// stage needs no host round trip.
+template <class T>
+__global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ c, int64_t ldc, int l, T* vg, int64_t ldv,
+                                                          T* m1, int64_t ld1, T* m2, int64_t ld2, T* s_out, int k, T tol,
+                                                          int max_sweeps, int* info) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int LP = l | 1;
+  T* w = (T*)smem;
+  T* sigma = w + (size_t)l * LP;
+  int* order = (int*)(sigma + l + 2);
+  int* flag = order + l + 2;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < l * l; idx += 1024) {
+    const int j = idx / l, i = idx - j * l;
+    w[j * LP + i] = c[(int64_t)j * ldc + i];
+    vg[(int64_t)j * ldv + i] = (i == j) ? (T)1 : (T)0;
+  }
+  __syncthreads();
+  const int n = (l + 1) & ~1;  // players in the tournament (one dummy when l is odd)
+  const int npairs = n / 2;
+  const int group = tid >> 4, gl = tid & 15;
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int step = 0; step < n - 1; ++step) {
+      for (int pr = group; pr < npairs; pr += 64) {
+        int p, q;
+        if (pr == 0) {
+          p = n - 1;
+          q = step;
+        } else {
+          p = (step + pr) % (n - 1);
+          q = (step - pr + (n - 1)) % (n - 1);
+        }
+        if (p > q) {
+          const int t_ = p;
+          p = q;
+          q = t_;
+        }
+        if (q >= l) continue;  // dummy player
+        T* wp = w + p * LP;
+        T* wq = w + q * LP;
+        T a = 0, b = 0, g = 0;
+        for (int i = gl; i < l; i += 16) {
+          const T x = wp[i], y = wq[i];
+          a += x * x;
+          b += y * y;
+          g += x * y;
+        }
+#pragma unroll
+        for (int msk = 1; msk < 16; msk <<= 1) {
+          a += __shfl_xor(a, msk, 16);
+          b += __shfl_xor(b, msk, 16);
+          g += __shfl_xor(g, msk, 16);
+        }
+        const T ab = sqrt(a * b);
+        if (!(fabs(g) > tol * ab) || ab == (T)0) continue;
+        const T zeta = (b - a) / ((T)2 * g);
+        const T t = (zeta >= (T)0 ? (T)1 : (T)-1) / (fabs(zeta) + sqrt((T)1 + zeta * zeta));
+        const T cs = (T)1 / sqrt((T)1 + t * t);
+        const T sn = cs * t;
+        T* vp = vg + (int64_t)p * ldv;
+        T* vq = vg + (int64_t)q * ldv;
+        for (int i = gl; i < l; i += 16) {
+          const T x = wp[i], y = wq[i];
+          wp[i] = cs * x - sn * y;
+          wq[i] = sn * x + cs * y;
+          const T vx = vp[i], vy = vq[i];
+          vp[i] = cs * vx - sn * vy;
+          vq[i] = sn * vx + cs * vy;
+        }
+        if (gl == 0) *flag = 1;
+      }
+      __syncthreads();
+    }
+    const int rotated = *flag;
+    __syncthreads();
+    if (!rotated) break;
+  }
+  // singular values and descending order
+  for (int j = group; j < l; j += 64) {
+    T a = 0;
+    for (int i = gl; i < l; i += 16) {
+      const T x = w[j * LP + i];
+      a += x * x;
+    }
+#pragma unroll
+    for (int msk = 1; msk < 16; msk <<= 1) a += __shfl_xor(a, msk, 16);
+    if (gl == 0) sigma[j] = sqrt(a);
+  }
+  __syncthreads();
+  for (int j = tid; j < l; j += 1024) {
+    const T sj = sigma[j];
+    int r = 0;
+    for (int i = 0; i < l; ++i) {
+      const T si = sigma[i];
+      r += (si > sj || (si == sj && i < j)) ? 1 : 0;
+    }
+    order[r] = j;
+  }
+  __syncthreads();
+  for (int r = group; r < k; r += 64) {
+    const int j = order[r];
+    const T sj = sigma[j];
+    const T inv = sj > (T)0 ? (T)1 / sj : (T)0;
+    for (int i = gl; i < l; i += 16) {
+      m2[(int64_t)r * ld2 + i] = w[j * LP + i] * inv;
+      m1[(int64_t)r * ld1 + i] = vg[(int64_t)j * ldv + i];
+    }
+    if (gl == 0) s_out[r] = sj;
+  }
+  if (tid == 0) info[0] = sweep;
+}
+__host__ __device__ inline size_t jacobi_lds_bytes(int l, size_t esz) {
+  return (size_t)l * (l | 1) * esz + (size_t)(l + 2) * esz + (size_t)(l + 2) * sizeof(int) + 64;
+}
+
 // ---- layout helpers --------------------------------------------------------------------------
 // dst[r * ldd + c] = src[r * rs + c * cs]   (repack any strided matrix to padded row-major)
 template <class T>

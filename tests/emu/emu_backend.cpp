@@ -162,6 +162,12 @@ class EmuDev {
   template <class T>
   void store_values(const T* src, int64_t n, T* dst, bool) { std::memcpy(dst, src, sizeof(T) * n); }
   template <class T>
+  void copy_values_out(const T* src, int64_t n, T* dst, bool) { std::memcpy(dst, src, sizeof(T) * n); }
+  template <class T>
+  void small_svd(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev) {
+    small_svd_host(*this, c, l, k, m1, m2, s_dev);
+  }
+  template <class T>
   void copy_out(const Skinny<T>& src, int64_t ncols, T* dst, int64_t ldd, bool transpose, bool) {
     for (int64_t c = 0; c < ncols; ++c)
       for (int64_t r = 0; r < src.rows; ++r) {
