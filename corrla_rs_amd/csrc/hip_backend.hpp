@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -71,12 +72,11 @@ class HipDev {
     CORRLA_HIP(hipMemsetAsync(zero_page_, 0, 256, stream));
     set_lds_attrs<float>();
     set_lds_attrs<double>();
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
+    set_jacobi_attrs<float>();
+    set_jacobi_attrs<double>();
     split_nn_override_ = env_int("CORRLA_SPLIT_NN", 0);
     split_tn_override_ = env_int("CORRLA_SPLIT_TN", 0);
+    mw_override_ = env_int("CORRLA_MW", 0);
   }
   ~HipDev() {
     (void)hipSetDevice(device);
@@ -244,18 +244,41 @@ class HipDev {
   // SVD of the l x l core (random_svd.rs:89): device Jacobi when W fits in LDS, host Jacobi otherwise
   template <class T>
   void small_svd(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev) {
-    const size_t lds = k::jacobi_lds_bytes((int)l, sizeof(T));
-    if (lds > (size_t)160 * 1024 || env_int("CORRLA_HOST_SVD", 0)) {
+    constexpr size_t kLdsMax = (size_t)160 * 1024;
+    const size_t lds2 = k::jacobi_lds_bytes((int)l, sizeof(T), true);
+    const size_t lds1 = k::jacobi_lds_bytes((int)l, sizeof(T), false);
+    if (lds1 > kLdsMax || l > k::kJacobiMaxL || env_int("CORRLA_HOST_SVD", 0)) {
       small_svd_host(*this, c, l, k, m1, m2, s_dev);
       return;
     }
     const int64_t ldv = round_up(l, 16);
     T* vg = (T*)alloc_bytes((size_t)ldv * l * sizeof(T));
     int* info = (int*)alloc_bytes(sizeof(int) * 4);
-    const T tol = (T)(std::sqrt((double)l) * (double)std::numeric_limits<T>::epsilon());
-    hipLaunchKernelGGL((k::jacobi_svd_kernel<T>), dim3(1), dim3(1024), lds, stream, (const T*)c.p, c.ld, (int)l, vg, ldv,
-                       m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, 40, info);
+    const double eps = (double)std::numeric_limits<T>::epsilon();
+    const T tol = (T)(std::sqrt((double)l) * eps);
+    const T tol_early = (T)std::sqrt(eps);  // quadratic convergence: a sweep that starts below this ends below tol
+    const bool v_lds = lds2 <= kLdsMax;
+    const size_t lds = v_lds ? lds2 : lds1;
+#define CORRLA_JACOBI(VL, G, E)                                                                                      \
+  hipLaunchKernelGGL((k::jacobi_svd_kernel<T, VL, G, E>), dim3(1), dim3(1024), lds, stream, (const T*)c.p, c.ld, (int)l, \
+                     vg, ldv, m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, tol_early, 40, info)
+    if (l <= 128) {
+      if (v_lds) CORRLA_JACOBI(true, 16, 8); else CORRLA_JACOBI(false, 16, 8);
+    } else if (l <= 144 && sizeof(T) == 4) {
+      if (v_lds) CORRLA_JACOBI(true, 8, 18); else CORRLA_JACOBI(false, 8, 18);
+    } else if (l <= 144) {
+      if (v_lds) CORRLA_JACOBI(true, 16, 9); else CORRLA_JACOBI(false, 16, 9);
+    } else {
+      if (v_lds) CORRLA_JACOBI(true, 16, 12); else CORRLA_JACOBI(false, 16, 12);
+    }
+#undef CORRLA_JACOBI
     CORRLA_HIP(hipGetLastError());
+    if (env_int("CORRLA_DEBUG", 0)) {
+      int h[4] = {0, 0, 0, 0};
+      CORRLA_HIP(hipMemcpyAsync(h, info, sizeof(int), hipMemcpyDeviceToHost, stream));
+      sync();
+      std::fprintf(stderr, "[corrla] jacobi_svd l=%d sweeps=%d v_in_lds=%d\n", (int)l, h[0], (int)v_lds);
+    }
   }
   // skinny (rows x ncols) -> column-major destination, optionally transposed (ncols x rows)
   template <class T>
@@ -343,7 +366,7 @@ class HipDev {
   };
   std::vector<Chunk> chunks_;
   void* zero_page_ = nullptr;
-  int split_nn_override_ = 0, split_tn_override_ = 0;
+  int split_nn_override_ = 0, split_tn_override_ = 0, mw_override_ = 0;
 
   static void check_grid(const dim3& g) {
     if (g.y > 65535u || g.z > 65535u) throw Error(ST_EINVAL, "problem too large for the launch grid");
@@ -351,9 +374,24 @@ class HipDev {
 
   template <class T, int NT>
   static void set_lds_attr_one() {
-    const int bytes = k::gemm_lds_bytes(NT);
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_nn_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_tn_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_nn_kernel<T, 1, NT>, attr, k::gemm_lds_bytes(1, NT)));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_tn_kernel<T, 1, NT>, attr, k::gemm_lds_bytes(1, NT)));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_nn_kernel<T, 2, NT>, attr, k::gemm_lds_bytes(2, NT)));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_tn_kernel<T, 2, NT>, attr, k::gemm_lds_bytes(2, NT)));
+  }
+  template <class T>
+  static void set_jacobi_attrs() {
+    const int lds = 160 * 1024;
+    const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 16, 8>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 16, 8>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 8, 18>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 8, 18>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 16, 9>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 16, 9>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 16, 12>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 16, 12>, attr, lds));
   }
   template <class T>
   static void set_lds_attrs() {
@@ -368,28 +406,43 @@ class HipDev {
     set_lds_attr_one<T, 9>();
   }
 
-  int choose_split(bool tn, int64_t outer_tiles, int nblk, int tiles_total) const {
+  // Launch geometry: MW (16-wide outer tiles per wave), nsplit (split of the reduction into slabs).
+  // One workgroup is resident per CU at the large column blockings, so aim for >= num_cus
+  // workgroups; prefer the MW = 2 shape (fewer skinny-operand bytes per MFMA) whenever the
+  // reduction is long enough to make up the workgroup count by splitting it.
+  void choose_geometry(bool tn, int64_t outer_n, int nblk, int tiles_total, int* mw_out, int* nsplit_out) const {
     const int ov = tn ? split_tn_override_ : split_nn_override_;
-    int ns;
+    int mw = (outer_n >= 128 && tiles_total >= 8) ? 2 : 1;
+    if (mw_override_ > 0) mw = mw_override_;
+    const int64_t outer_tiles = (outer_n + 64 * mw - 1) / (64 * mw);
+    const int64_t wgs = outer_tiles * nblk;
+    int ns = 1;
     if (ov > 0) {
       ns = ov;
-    } else {
-      const int64_t wgs = outer_tiles * nblk;
-      if (wgs >= num_cus) return 1;
-      ns = (int)((2 * (int64_t)num_cus + wgs - 1) / wgs);
+    } else if (wgs < num_cus) {
+      ns = (int)((num_cus + wgs - 1) / wgs);
+      if (wgs * ns < 2 * (int64_t)num_cus && wgs < num_cus / 4) ns *= 2;  // small grids: two waves of WGs
       ns = std::min(ns, std::max(1, tiles_total / 4));
     }
     ns = std::max(1, std::min(ns, tiles_total));
-    return std::min(ns, 65535);
+    *mw_out = mw;
+    *nsplit_out = std::min(ns, 65535);
   }
 
-  template <class T, int NT>
+  template <class T, int MW, int NT>
   void launch_one(bool tn, dim3 grid, const k::GemmArgs<T>& a) {
-    const int lds = k::gemm_lds_bytes(NT);
+    const int lds = k::gemm_lds_bytes(MW, NT);
     if (tn)
-      hipLaunchKernelGGL((k::gemm_tn_kernel<T, NT>), grid, dim3(256), lds, stream, a);
+      hipLaunchKernelGGL((k::gemm_tn_kernel<T, MW, NT>), grid, dim3(256), lds, stream, a);
     else
-      hipLaunchKernelGGL((k::gemm_nn_kernel<T, NT>), grid, dim3(256), lds, stream, a);
+      hipLaunchKernelGGL((k::gemm_nn_kernel<T, MW, NT>), grid, dim3(256), lds, stream, a);
+  }
+  template <class T, int NT>
+  void launch_mw(bool tn, int mw, dim3 grid, const k::GemmArgs<T>& a) {
+    if (mw == 2)
+      launch_one<T, 2, NT>(tn, grid, a);
+    else
+      launch_one<T, 1, NT>(tn, grid, a);
   }
 
   // out (outer_n x L) = scale * op(R) * X; `outer_n` = surviving dimension of R, `red_n` = reduced one
@@ -408,9 +461,10 @@ class HipDev {
     if (tiles64 > 0x7fffffff) throw Error(ST_EINVAL, "reduction dimension too large");
     const int tiles_total = (int)tiles64;
     if (x.ld < (int64_t)tiles_total * KT) throw Error(ST_EINVAL, "internal: skinny leading dimension too small");
-    const int64_t outer_tiles = (outer_n + k::kOuterTile - 1) / k::kOuterTile;
+    int mw = 1, nsplit = 1;
+    choose_geometry(tn, outer_n, cb.nblk, tiles_total, &mw, &nsplit);
+    const int64_t outer_tiles = (outer_n + 64 * mw - 1) / (64 * mw);
     if (outer_tiles > 0x7fffffff) throw Error(ST_EINVAL, "outer dimension too large");
-    const int nsplit = choose_split(tn, outer_tiles, cb.nblk, tiles_total);
     k::GemmArgs<T> a;
     a.r = r.p;
     a.r_rows = r.rows;
@@ -432,15 +486,15 @@ class HipDev {
     dim3 grid((unsigned)outer_tiles, (unsigned)cb.nblk, (unsigned)nsplit);
     check_grid(grid);
     switch (cb.nt) {
-      case 1: launch_one<T, 1>(tn, grid, a); break;
-      case 2: launch_one<T, 2>(tn, grid, a); break;
-      case 3: launch_one<T, 3>(tn, grid, a); break;
-      case 4: launch_one<T, 4>(tn, grid, a); break;
-      case 5: launch_one<T, 5>(tn, grid, a); break;
-      case 6: launch_one<T, 6>(tn, grid, a); break;
-      case 7: launch_one<T, 7>(tn, grid, a); break;
-      case 8: launch_one<T, 8>(tn, grid, a); break;
-      case 9: launch_one<T, 9>(tn, grid, a); break;
+      case 1: launch_mw<T, 1>(tn, mw, grid, a); break;
+      case 2: launch_mw<T, 2>(tn, mw, grid, a); break;
+      case 3: launch_mw<T, 3>(tn, mw, grid, a); break;
+      case 4: launch_mw<T, 4>(tn, mw, grid, a); break;
+      case 5: launch_mw<T, 5>(tn, mw, grid, a); break;
+      case 6: launch_mw<T, 6>(tn, mw, grid, a); break;
+      case 7: launch_mw<T, 7>(tn, mw, grid, a); break;
+      case 8: launch_mw<T, 8>(tn, mw, grid, a); break;
+      case 9: launch_mw<T, 9>(tn, mw, grid, a); break;
       default: throw Error(ST_EINVAL, "internal: bad column blocking");
     }
     CORRLA_HIP(hipGetLastError());

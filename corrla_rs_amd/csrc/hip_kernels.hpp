@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace corrla {
 namespace k {
 
@@ -71,12 +73,15 @@ struct MT<double> {
   static __device__ __forceinline__ int tswz(int row) { return ((row >> 1) & 1) << 3; }
 };
 
-constexpr int kRowBytes = 256;            // LDS row of the k-contiguous images
-constexpr int kOuterTile = 64;            // outer indices per workgroup (4 waves x 16)
-constexpr int kBigTileBytes = 64 * 256;   // 16 KiB: big-operand tile per stage (both kernels, both dtypes)
-
-__host__ __device__ constexpr int stage_bytes(int nt) { return kBigTileBytes + nt * 16 * kRowBytes; }
-__host__ __device__ constexpr int gemm_lds_bytes(int nt) { return 2 * stage_bytes(nt); }
+constexpr int kRowBytes = 256;  // LDS row of the k-contiguous images
+// A workgroup owns 64*MW outer indices (4 waves x MW 16-wide MFMA tiles each).  MW = 2 halves the
+// skinny-operand bytes staged per MFMA (the per-CU global->LDS fill rate, ~11 B/clk, is what bounds
+// the MW = 1 shape at 144 columns: 52 KiB per 4608 MFMA cycles); MW = 1 keeps small problems spread
+// over more workgroups.
+__host__ __device__ constexpr int outer_tile(int mw) { return 64 * mw; }
+__host__ __device__ constexpr int big_tile_bytes(int mw) { return 64 * 256 * mw; }
+__host__ __device__ constexpr int stage_bytes(int mw, int nt) { return big_tile_bytes(mw) + nt * 16 * kRowBytes; }
+__host__ __device__ constexpr int gemm_lds_bytes(int mw, int nt) { return 2 * stage_bytes(mw, nt); }
 
 template <class T>
 struct GemmArgs {
@@ -100,26 +105,52 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// Stage NT*16 rows (one per skinny column) x 256 B of a column-major skinny operand: row = column
-// index, contiguous along the reduction index.  Never out of range (padding is allocated + zero).
-template <class T, int NT>
-__device__ __forceinline__ void stage_skinny(char* xt, const T* x, int64_t x_ld, int64_t col0, int64_t k0, int wave,
-                                             int lane) {
-  constexpr int VEC = MT<T>::VEC;
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {  // NT*4 one-KiB chunks over 4 waves
-    const int c = wave + 4 * i;
-    const int row = 4 * c + (lane >> 4);
-    const int ls = (lane & 15) ^ (row & 15);
-    const T* src = x + (col0 + row) * x_ld + k0 + ls * VEC;
-    glds16(src, xt + c * 1024);
+
+// ---- explicit LDS fragment pipeline (cdna_hip_programming.md 5.7) --------------------------------
+// hipcc (ROCm 7.2) brackets every LDS fragment read of this loop with s_waitcnt lgkmcnt(0), which
+// exposes the full LDS latency to the single wave per SIMD.  The fragment reads are therefore
+// issued as inline-asm ds_read_* PD steps ahead of their MFMAs, and retired by hand-counted
+// s_waitcnt lgkmcnt(N) statements that take the fragment as a "+v" operand: the data dependence
+// keeps every consumer below its wait, and volatile asm keeps reads and waits in program order.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
   }
+}
+template <int OFF, class V>
+__device__ __forceinline__ void lds_read_b128(V& d, unsigned addr) {
+  static_assert(sizeof(V) == 16 && OFF >= 0 && OFF < 65536, "ds_read_b128 operand");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_elem(float& d, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 offset");
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_elem(double& d, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b64 offset");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N, class V>
+__device__ __forceinline__ void lds_wait(V& frag) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N) : "memory");
+}
+template <class V>
+__device__ __forceinline__ void lds_tie(V& frag) {  // frag was retired by an earlier (in-order) wait
+  asm volatile("" : "+v"(frag));
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
 }
 
 template <class T, int NT>
 __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename MT<T>::acc_t (&acc)[NT], int64_t outer0,
-                                           int64_t outer_limit, int64_t col0, int wave, int lane) {
-  const int64_t outer = outer0 + 16 * wave + (lane & 15);
+                                           int64_t outer_limit, int64_t col0, int lane) {
+  const int64_t outer = outer0 + (lane & 15);
   if (outer >= outer_limit) return;
   T* dst;
   T sc = (T)1;
@@ -142,148 +173,267 @@ __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename 
 // ---------------------------------------------------------------------------------------------
 // gemm_nn: grid = (ceil(R_rows/64), column blocks, nsplit)
 // ---------------------------------------------------------------------------------------------
-template <class T, int NT>
+template <class T, int MW, int NT>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs<T> g) {
   typedef typename MT<T>::acc_t acc_t;
   typedef typename MT<T>::vec_t vec_t;
   constexpr int VEC = MT<T>::VEC;
   constexpr int KT = MT<T>::KT;
-  constexpr int STAGE = stage_bytes(NT);
+  constexpr int STAGE = stage_bytes(MW, NT);
+  constexpr int BIG = big_tile_bytes(MW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row0 = (int64_t)blockIdx.x * kOuterTile;
+  const int64_t row0 = (int64_t)blockIdx.x * outer_tile(MW);
   const int64_t col0 = (int64_t)blockIdx.y * (NT * 16);
   const int t_begin = blockIdx.z * g.tiles_per_split;
   const int t_end = min(t_begin + g.tiles_per_split, g.tiles_total);
   const int nk = t_end - t_begin;
 
-  acc_t acc[NT];
+  acc_t acc[MW][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (acc_t){0, 0, 0, 0};
+  for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[mw][t] = (acc_t){0, 0, 0, 0};
 
-  auto stage = [&](int buf, int kt) {
+  // Per-lane DMA sources, hoisted out of the k loop.  Chunk c = wave + 4*i covers tile rows 4c..4c+3;
+  // this lane fills physical 16-byte slot (lane & 15) of row 4c + (lane >> 4) with logical slot
+  // ls = slot ^ (row & 15) -- and (row & 15) = (4*wave + (lane >> 4)) & 15 does not depend on i.
+  const int ls = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
+  const int64_t koff = (int64_t)ls * VEC;
+  const T* bigp[4 * MW];
+  bool bigok[4 * MW];
+#pragma unroll
+  for (int i = 0; i < 4 * MW; ++i) {
+    const int64_t grow = row0 + 4 * (wave + 4 * i) + (lane >> 4);
+    bigok[i] = grow < g.r_rows;
+    bigp[i] = g.r + grow * g.r_ld + koff;
+  }
+  const T* skp[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) skp[i] = g.x + (col0 + 4 * (wave + 4 * i) + (lane >> 4)) * g.x_ld + koff;
+
+  // issue slice `part` (0..3) of the DMA for reduction tile kt into buffer `buf`
+  auto stage_part = [&](int buf, int kt, int part) {
     char* rt = smem + buf * STAGE;
     const int64_t k0 = (int64_t)kt * KT;
+    const bool kin = k0 + koff < g.r_cols_readable;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // 16 one-KiB chunks over 4 waves
-      const int c = wave + 4 * i;
-      const int row = 4 * c + (lane >> 4);
-      const int ls = (lane & 15) ^ (row & 15);
-      const int64_t grow = row0 + row;
-      const int64_t kk = k0 + ls * VEC;
-      const T* src = (grow < g.r_rows && kk < g.r_cols_readable) ? g.r + grow * g.r_ld + kk : g.zero;
-      glds16(src, rt + c * 1024);
+    for (int i = 0; i < 4 * MW; ++i) {
+      if ((i & 3) != part) continue;
+      const T* src = (bigok[i] && kin) ? bigp[i] + k0 : g.zero;
+      glds16(src, rt + (wave + 4 * i) * 1024);
     }
-    stage_skinny<T, NT>(rt + kBigTileBytes, g.x, g.x_ld, col0, k0, wave, lane);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      if ((i & 3) != part) continue;
+      glds16(skp[i] + k0, rt + BIG + (wave + 4 * i) * 1024);
+    }
   };
 
-  auto compute = [&](int buf) {
-    const char* rt = smem + buf * STAGE;
-    const char* xt = rt + kBigTileBytes;
-    const int c = lane & 15, kq = lane >> 4;
-    const char* brow = rt + (16 * wave + c) * kRowBytes;
-    const char* arow = xt + c * kRowBytes;
+  // wave w owns tile rows [16*MW*w, 16*MW*(w+1)); the next tile's DMA issue is spread over the four
+  // fragment groups so it runs in the shadow of the MFMAs instead of ahead of them
+  // Fragment read addresses (bytes inside a stage), lane-invariant across tiles: for fragment group
+  // gq this lane reads 16-byte slot (4*gq + kq) ^ c of its row in both images.
+  const int fc = lane & 15, fkq = lane >> 4;
+  const unsigned lds0 = lds_addr(smem);
+  unsigned a_off[4], b_off[4];
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const int so = ((4 * gq + kq) ^ c) << 4;
-      const vec_t b = *(const vec_t*)(brow + so);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const vec_t a = *(const vec_t*)(arow + t * 16 * kRowBytes + so);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[t] = MT<T>::mma(a[j], b[j], acc[t]);
+  for (int gq = 0; gq < 4; ++gq) {
+    const unsigned so = (unsigned)(((4 * gq + fkq) ^ fc) << 4);
+    a_off[gq] = lds0 + BIG + fc * kRowBytes + so;
+    b_off[gq] = lds0 + (16 * MW * wave + fc) * kRowBytes + so;
+  }
+
+  // Step st = gq*NT + t consumes one skinny fragment a(st) and the MW big-operand fragments b(gq) in
+  // MW*VEC MFMAs.  Reads for step st+PD are issued before the MFMAs of step st; the wait for step
+  // st leaves exactly the younger reads (steps st+1..st+PD) in flight.
+  auto compute = [&](int buf, bool prefetch, int nbuf, int nkt) {
+    constexpr int NS = 4 * NT;
+    constexpr int PD = (MW == 1) ? 3 : 2;
+    const unsigned sb = (unsigned)(buf * STAGE);
+    vec_t afr[NS];
+    vec_t bfr[4][MW];
+    auto read_step = [&](auto ic) {  // all reads that step `st` needs and that are not issued yet
+      constexpr int st = decltype(ic)::value;
+      constexpr int gq = st / NT, t = st % NT;
+      if constexpr (t == 0) {
+        static_for<0, MW>([&](auto im) {
+          constexpr int mw = decltype(im)::value;
+          lds_read_b128<mw * 16 * kRowBytes>(bfr[gq][mw], b_off[gq] + sb);
+        });
       }
-    }
+      lds_read_b128<t * 16 * kRowBytes>(afr[st], a_off[gq] + sb);
+    };
+    static_for<0, (PD < NS ? PD : NS)>(read_step);
+    static_for<0, NS>([&](auto ic) {
+      constexpr int st = decltype(ic)::value;
+      constexpr int gq = st / NT, t = st % NT;
+      if constexpr (st + PD < NS) read_step(std::integral_constant<int, st + PD>{});
+      if constexpr (t == 0) {
+        if (prefetch) stage_part(nbuf, nkt, gq);
+      }
+      // reads younger than a(st): steps st+1 .. min(st+PD, NS-1), each 1 read (+MW when it opens a group)
+      constexpr int last = (st + PD < NS) ? st + PD : NS - 1;
+      constexpr int groups = last / NT - gq;  // fragment groups opened by the younger steps
+      constexpr int younger = (last - st) + groups * MW;
+      lds_wait<(younger < 15 ? younger : 15)>(afr[st]);  // a smaller count only waits for more
+      if constexpr (t == 0) {
+        static_for<0, MW>([&](auto im) { lds_tie(bfr[gq][decltype(im)::value]); });
+      }
+#pragma unroll
+      for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(afr[st][j], bfr[gq][mw][j], acc[mw][t]);
+    });
   };
 
-  if (nk > 0) stage(0, t_begin);
+  if (nk > 0) {
+#pragma unroll
+    for (int part = 0; part < 4; ++part) stage_part(0, t_begin, part);
+  }
   for (int i = 0; i < nk; ++i) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile i has landed for every wave; everyone is done reading buffer (i+1)&1
-    if (i + 1 < nk) stage((i + 1) & 1, t_begin + i + 1);
-    compute(i & 1);
+    compute(i & 1, i + 1 < nk, (i + 1) & 1, t_begin + i + 1);
   }
-  store_tile<T, NT>(g, acc, row0, g.r_rows, col0, wave, lane);
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw)
+    store_tile<T, NT>(g, acc[mw], row0 + 16 * MW * wave + 16 * mw, g.r_rows, col0, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
 // gemm_tn: grid = (ceil(R_cols/64), column blocks, nsplit); reduction over the rows of R
 // ---------------------------------------------------------------------------------------------
-template <class T, int NT>
+template <class T, int MW, int NT>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
   typedef typename MT<T>::acc_t acc_t;
   typedef typename MT<T>::vec_t vec_t;
   constexpr int VEC = MT<T>::VEC;
   constexpr int KT = MT<T>::KT;
-  constexpr int STAGE = stage_bytes(NT);
-  constexpr int RBT = 64 * (int)sizeof(T);  // bytes per row of the big tile (64 outer columns)
-  constexpr int LPR = RBT / 16;             // lanes per row in one DMA instruction
-  constexpr int RPC = 64 / LPR;             // rows per 1-KiB DMA chunk
+  constexpr int STAGE = stage_bytes(MW, NT);
+  constexpr int BIG = big_tile_bytes(MW);
+  constexpr int RBT = 64 * MW * (int)sizeof(T);  // bytes per row of the big tile (64*MW outer columns)
+  constexpr int LPR = RBT / 16;                  // lanes per row in one DMA instruction (16..128)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t n0 = (int64_t)blockIdx.x * kOuterTile;
+  const int64_t n0 = (int64_t)blockIdx.x * outer_tile(MW);
   const int64_t col0 = (int64_t)blockIdx.y * (NT * 16);
   const int t_begin = blockIdx.z * g.tiles_per_split;
   const int t_end = min(t_begin + g.tiles_per_split, g.tiles_total);
   const int nk = t_end - t_begin;
 
-  acc_t acc[NT];
+  acc_t acc[MW][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (acc_t){0, 0, 0, 0};
+  for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[mw][t] = (acc_t){0, 0, 0, 0};
 
-  auto stage = [&](int buf, int mt) {
+  // Per-lane DMA sources, hoisted out of the reduction loop.  The big tile is a row-linear LDS image
+  // of KT reduction rows x (64*MW outer columns); chunk c = wave + 4*i, 16-byte slot lin = 64c + lane.
+  const T* bigp[4 * MW];
+  int bigrow[4 * MW];
+  bool bigok[4 * MW];
+#pragma unroll
+  for (int i = 0; i < 4 * MW; ++i) {
+    const int lin = (wave + 4 * i) * 64 + lane;
+    const int row = lin / LPR;
+    const int lsb = (lin % LPR) ^ MT<T>::tswz(row);
+    const int64_t nn = n0 + (int64_t)lsb * VEC;
+    bigrow[i] = row;
+    bigok[i] = nn < g.r_cols_readable;
+    bigp[i] = g.r + (int64_t)row * g.r_ld + nn;
+  }
+  const int ls = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
+  const T* skp[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) skp[i] = g.x + (col0 + 4 * (wave + 4 * i) + (lane >> 4)) * g.x_ld + (int64_t)ls * VEC;
+
+  auto stage_part = [&](int buf, int mt, int part) {
     char* rt = smem + buf * STAGE;
     const int64_t m0 = (int64_t)mt * KT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = wave + 4 * i;
-      const int row = RPC * c + lane / LPR;
-      const int ls = (lane % LPR) ^ MT<T>::tswz(row);
-      const int64_t grow = m0 + row;
-      const int64_t nn = n0 + ls * VEC;
-      const T* src = (grow < g.r_rows && nn < g.r_cols_readable) ? g.r + grow * g.r_ld + nn : g.zero;
-      glds16(src, rt + c * 1024);
+    for (int i = 0; i < 4 * MW; ++i) {
+      if ((i & 3) != part) continue;
+      const T* src = (bigok[i] && m0 + bigrow[i] < g.r_rows) ? bigp[i] + m0 * g.r_ld : g.zero;
+      glds16(src, rt + (wave + 4 * i) * 1024);
     }
-    stage_skinny<T, NT>(rt + kBigTileBytes, g.x, g.x_ld, col0, m0, wave, lane);
-  };
-
-  auto compute = [&](int buf) {
-    const char* rt = smem + buf * STAGE;
-    const char* xt = rt + kBigTileBytes;
-    const int c = lane & 15, kq = lane >> 4;
-    const int ncol = 16 * wave + c;           // outer column inside the tile
-    const int nls = ncol / VEC;               // its logical 16-byte slot
-    const int noff = (ncol % VEC) * (int)sizeof(T);
-    const char* arow = xt + c * kRowBytes;
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const int slot = 4 * gq + kq;
-      T b[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const int mloc = slot * VEC + j;
-        b[j] = *(const T*)(rt + mloc * RBT + ((nls ^ MT<T>::tswz(mloc)) << 4) + noff);
-      }
-      const int so = (slot ^ c) << 4;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const vec_t a = *(const vec_t*)(arow + t * 16 * kRowBytes + so);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[t] = MT<T>::mma(a[j], b[j], acc[t]);
-      }
+    for (int i = 0; i < NT; ++i) {
+      if ((i & 3) != part) continue;
+      glds16(skp[i] + m0, rt + BIG + (wave + 4 * i) * 1024);
     }
   };
 
-  if (nk > 0) stage(0, t_begin);
+  // wave w owns tile columns [16*MW*w, 16*MW*(w+1))
+  // Fragment read addresses (bytes inside a stage), lane-invariant across tiles.  Skinny image: as in
+  // gemm_nn.  Big image: element (reduction row mloc, outer column ncol) sits at
+  // mloc*RBT + ((ncol/VEC) ^ tswz(mloc))*16 + (ncol%VEC)*sizeof(T); for this lane mloc =
+  // (4*gq + kq)*VEC + j, and tswz(mloc) only depends on kq, so one base per mw plus immediates.
+  const int fc = lane & 15, fkq = lane >> 4;
+  const unsigned lds0 = lds_addr(smem);
+  unsigned a_off[4], b_off[MW];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) a_off[gq] = lds0 + BIG + fc * kRowBytes + (unsigned)(((4 * gq + fkq) ^ fc) << 4);
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw) {
+    const int ncol = 16 * MW * wave + 16 * mw + fc;
+    b_off[mw] = lds0 + (unsigned)(fkq * VEC * RBT + (((ncol / VEC) ^ MT<T>::tswz(fkq * VEC)) << 4) +
+                                  (ncol % VEC) * (int)sizeof(T));
+  }
+
+  auto compute = [&](int buf, bool prefetch, int nbuf, int nmt) {
+    constexpr int NS = 4 * NT;
+    constexpr int PD = (MW == 1) ? 3 : 2;
+    const unsigned sb = (unsigned)(buf * STAGE);
+    vec_t afr[NS];
+    T bfr[4][MW][VEC];
+    auto read_step = [&](auto ic) {
+      constexpr int st = decltype(ic)::value;
+      constexpr int gq = st / NT, t = st % NT;
+      if constexpr (t == 0) {
+        static_for<0, MW * VEC>([&](auto iq) {
+          constexpr int mw = decltype(iq)::value / VEC, j = decltype(iq)::value % VEC;
+          lds_read_elem<(4 * gq * VEC + j) * RBT>(bfr[gq][mw][j], b_off[mw] + sb);
+        });
+      }
+      lds_read_b128<t * 16 * kRowBytes>(afr[st], a_off[gq] + sb);
+    };
+    static_for<0, (PD < NS ? PD : NS)>(read_step);
+    static_for<0, NS>([&](auto ic) {
+      constexpr int st = decltype(ic)::value;
+      constexpr int gq = st / NT, t = st % NT;
+      if constexpr (st + PD < NS) read_step(std::integral_constant<int, st + PD>{});
+      if constexpr (t == 0) {
+        if (prefetch) stage_part(nbuf, nmt, gq);
+      }
+      constexpr int last = (st + PD < NS) ? st + PD : NS - 1;
+      constexpr int groups = last / NT - gq;
+      constexpr int younger = (last - st) + groups * MW * VEC;
+      lds_wait<(younger < 15 ? younger : 15)>(afr[st]);  // a smaller count only waits for more
+      if constexpr (t == 0) {
+        static_for<0, MW * VEC>([&](auto iq) { lds_tie(bfr[gq][decltype(iq)::value / VEC][decltype(iq)::value % VEC]); });
+      }
+#pragma unroll
+      for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(afr[st][j], bfr[gq][mw][j], acc[mw][t]);
+    });
+  };
+
+  if (nk > 0) {
+#pragma unroll
+    for (int part = 0; part < 4; ++part) stage_part(0, t_begin, part);
+  }
   for (int i = 0; i < nk; ++i) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (i + 1 < nk) stage((i + 1) & 1, t_begin + i + 1);
-    compute(i & 1);
+    compute(i & 1, i + 1 < nk, (i + 1) & 1, t_begin + i + 1);
   }
-  store_tile<T, NT>(g, acc, n0, g.r_cols, col0, wave, lane);
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw)
+    store_tile<T, NT>(g, acc[mw], n0 + 16 * MW * wave + 16 * mw, g.r_cols, col0, lane);
 }
 
 // out[col][i] = scale * sum_z slab[z][col][i], i < limit, col < ncols; fixed z order (deterministic)
@@ -391,23 +541,33 @@ __global__ void fill_normal_kernel(T* p, int64_t rows, int64_t cols, int64_t rs,
 
 // ---- SVD of the l x l core (random_svd.rs:89) on the device -------------------------------------
 // One-sided (Hestenes) Jacobi in ONE workgroup of 1024 threads: W = C lives in LDS (column-major,
-// odd pitch), the accumulated right rotations V live in global memory (L2-resident, same CU).  A
-// round-robin tournament gives n/2 disjoint column pairs per step; each pair is rotated by a 16-lane
-// group (64 pairs in flight), with the three dot products reduced by xor-shuffles inside the group.
-// On exit the columns of W are U_c * sigma and V = V_c with C = U_c diag(sigma) V_c^T.  The kernel
-// sorts sigma descending and writes sigma[:k], V_c[:, :k] (-> m1) and U_c[:, :k] (-> m2) directly into
-// the zero-padded skinny operands of the GEMMs that follow (U = Q * m1, V = Qb * m2), so the final
-// stage needs no host round trip.
-template <class T>
+// odd pitch) and so does the accumulated right-rotation matrix V when both fit (else V sits in
+// global memory, L2-resident, same CU).  A round-robin tournament gives n/2 disjoint column pairs
+// per step; each pair is rotated by a G-lane group (G = 16: 64 pairs in flight; G = 8 (f32, up to
+// 128 pairs): the whole step in ONE round), lane gl owning elements gl + G*e, e < E, of the four
+// columns involved.
+// They are loaded once with independent LDS reads, the three dot products are reduced by xor-
+// shuffles inside the group, and the rotation is applied in registers before the write-back.
+// Convergence is quadratic, so the sweep in which every |w_p.w_q| / (|w_p||w_q|) was already below
+// sqrt(tol) is the last one.  On exit the columns of W are U_c * sigma and V = V_c with
+// C = U_c diag(sigma) V_c^T.  The kernel sorts sigma descending and writes sigma[:k], V_c[:, :k]
+// (-> m1) and U_c[:, :k] (-> m2) directly into the zero-padded skinny operands of the GEMMs that
+// follow (U = Q * m1, V = Qb * m2), so the final stage needs no host round trip.
+template <class T, bool V_IN_LDS, int G, int E>
 __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ c, int64_t ldc, int l, T* vg, int64_t ldv,
                                                           T* m1, int64_t ld1, T* m2, int64_t ld2, T* s_out, int k, T tol,
-                                                          int max_sweeps, int* info) {
+                                                          T tol_early, int max_sweeps, int* info) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NG = 1024 / G;  // groups = pairs in flight
   const int LP = l | 1;
   T* w = (T*)smem;
-  T* sigma = w + (size_t)l * LP;
+  T* sigma = w + (size_t)l * LP * (V_IN_LDS ? 2 : 1);
   int* order = (int*)(sigma + l + 2);
-  int* flag = order + l + 2;
+  int* flag = order + l + 2;  // flag[0]: rotated this sweep, flag[1]: some pair above tol_early
+  if (V_IN_LDS) {
+    vg = w + (size_t)l * LP;
+    ldv = LP;
+  }
   const int tid = threadIdx.x;
   for (int idx = tid; idx < l * l; idx += 1024) {
     const int j = idx / l, i = idx - j * l;
@@ -417,13 +577,13 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
   __syncthreads();
   const int n = (l + 1) & ~1;  // players in the tournament (one dummy when l is odd)
   const int npairs = n / 2;
-  const int group = tid >> 4, gl = tid & 15;
+  const int group = tid / G, gl = tid % G;
   int sweep = 0;
   for (; sweep < max_sweeps; ++sweep) {
-    if (tid == 0) *flag = 0;
+    if (tid < 2) flag[tid] = 0;
     __syncthreads();
     for (int step = 0; step < n - 1; ++step) {
-      for (int pr = group; pr < npairs; pr += 64) {
+      for (int pr = group; pr < npairs; pr += NG) {
         int p, q;
         if (pr == 0) {
           p = n - 1;
@@ -437,55 +597,75 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
           p = q;
           q = t_;
         }
-        if (q >= l) continue;  // dummy player
+        if (q >= l) continue;  // the dummy player (uniform within the group)
         T* wp = w + p * LP;
         T* wq = w + q * LP;
-        T a = 0, b = 0, g = 0;
-        for (int i = gl; i < l; i += 16) {
-          const T x = wp[i], y = wq[i];
-          a += x * x;
-          b += y * y;
-          g += x * y;
-        }
-#pragma unroll
-        for (int msk = 1; msk < 16; msk <<= 1) {
-          a += __shfl_xor(a, msk, 16);
-          b += __shfl_xor(b, msk, 16);
-          g += __shfl_xor(g, msk, 16);
-        }
-        const T ab = sqrt(a * b);
-        if (!(fabs(g) > tol * ab) || ab == (T)0) continue;
-        const T zeta = (b - a) / ((T)2 * g);
-        const T t = (zeta >= (T)0 ? (T)1 : (T)-1) / (fabs(zeta) + sqrt((T)1 + zeta * zeta));
-        const T cs = (T)1 / sqrt((T)1 + t * t);
-        const T sn = cs * t;
         T* vp = vg + (int64_t)p * ldv;
         T* vq = vg + (int64_t)q * ldv;
-        for (int i = gl; i < l; i += 16) {
-          const T x = wp[i], y = wq[i];
-          wp[i] = cs * x - sn * y;
-          wq[i] = sn * x + cs * y;
-          const T vx = vp[i], vy = vq[i];
-          vp[i] = cs * vx - sn * vy;
-          vq[i] = sn * vx + cs * vy;
+        T x[E], y[E], vx[E], vy[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = gl + G * e;
+          const bool in = i < l;
+          x[e] = in ? wp[i] : (T)0;
+          y[e] = in ? wq[i] : (T)0;
+          vx[e] = in ? vp[i] : (T)0;
+          vy[e] = in ? vq[i] : (T)0;
         }
-        if (gl == 0) *flag = 1;
+        T a = 0, b = 0, g = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          a += x[e] * x[e];
+          b += y[e] * y[e];
+          g += x[e] * y[e];
+        }
+#pragma unroll
+        for (int msk = 1; msk < G; msk <<= 1) {
+          a += __shfl_xor(a, msk, G);
+          b += __shfl_xor(b, msk, G);
+          g += __shfl_xor(g, msk, G);
+        }
+        const T ab = sqrt(a * b);
+        const T ag = fabs(g);
+        if (ag > tol * ab && ab > (T)0) {
+          const T zeta = (b - a) / ((T)2 * g);
+          const T t = (zeta >= (T)0 ? (T)1 : (T)-1) / (fabs(zeta) + sqrt((T)1 + zeta * zeta));
+          const T cs = (T)1 / sqrt((T)1 + t * t);
+          const T sn = cs * t;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int i = gl + G * e;
+            if (i < l) {
+              wp[i] = cs * x[e] - sn * y[e];
+              wq[i] = sn * x[e] + cs * y[e];
+              vp[i] = cs * vx[e] - sn * vy[e];
+              vq[i] = sn * vx[e] + cs * vy[e];
+            }
+          }
+          if (gl == 0) {
+            flag[0] = 1;
+            if (ag > tol_early * ab) flag[1] = 1;
+          }
+        }
       }
       __syncthreads();
     }
-    const int rotated = *flag;
+    const int rotated = flag[0], big = flag[1];
     __syncthreads();
-    if (!rotated) break;
+    if (!rotated || !big) {
+      if (rotated) ++sweep;  // this sweep did (small, final) rotations
+      break;
+    }
   }
   // singular values and descending order
-  for (int j = group; j < l; j += 64) {
+  for (int j = group; j < l; j += NG) {
     T a = 0;
-    for (int i = gl; i < l; i += 16) {
-      const T x = w[j * LP + i];
-      a += x * x;
+    for (int i = gl; i < l; i += G) {
+      const T xx = w[j * LP + i];
+      a += xx * xx;
     }
 #pragma unroll
-    for (int msk = 1; msk < 16; msk <<= 1) a += __shfl_xor(a, msk, 16);
+    for (int msk = 1; msk < G; msk <<= 1) a += __shfl_xor(a, msk, G);
     if (gl == 0) sigma[j] = sqrt(a);
   }
   __syncthreads();
@@ -499,11 +679,11 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
     order[r] = j;
   }
   __syncthreads();
-  for (int r = group; r < k; r += 64) {
+  for (int r = group; r < k; r += NG) {
     const int j = order[r];
     const T sj = sigma[j];
     const T inv = sj > (T)0 ? (T)1 / sj : (T)0;
-    for (int i = gl; i < l; i += 16) {
+    for (int i = gl; i < l; i += G) {
       m2[(int64_t)r * ld2 + i] = w[j * LP + i] * inv;
       m1[(int64_t)r * ld1 + i] = vg[(int64_t)j * ldv + i];
     }
@@ -511,9 +691,10 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
   }
   if (tid == 0) info[0] = sweep;
 }
-__host__ __device__ inline size_t jacobi_lds_bytes(int l, size_t esz) {
-  return (size_t)l * (l | 1) * esz + (size_t)(l + 2) * esz + (size_t)(l + 2) * sizeof(int) + 64;
+__host__ __device__ inline size_t jacobi_lds_bytes(int l, size_t esz, bool v_in_lds) {
+  return (size_t)l * (l | 1) * esz * (v_in_lds ? 2 : 1) + (size_t)(l + 2) * esz + (size_t)(l + 2) * sizeof(int) + 64;
 }
+constexpr int kJacobiMaxL = 192;  // 16-lane groups x 12 elements per lane
 
 // ---- layout helpers --------------------------------------------------------------------------
 // dst[r * ldd + c] = src[r * rs + c * cs]   (repack any strided matrix to padded row-major)
