@@ -1,0 +1,50 @@
+"""Worker for tests/test_sharded_gloo.py: one rank of the row-sharded random_svd, run through the REAL
+driver (driver.hpp / capi_impl.hpp) on the test-only emulation backend, with the all-reduce exchange
+points served by torch.distributed (gloo) -- the same exchange points RCCL serves on GPUs."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.emu_harness import ALLREDUCE_FN, emu, emu_rsvd  # noqa: E402
+
+
+def main():
+    out_dir = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    calls = {"n": 0, "bytes": 0}
+
+    def allreduce(buf, count, is_f64):
+        dt = np.float64 if is_f64 else np.float32
+        arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double if is_f64 else C.c_float)), shape=(count,))
+        t = torch.from_numpy(arr)
+        dist.all_reduce(t)  # in place (shares memory with the C buffer)
+        calls["n"] += 1
+        calls["bytes"] += count * np.dtype(dt).itemsize
+
+    cb = ALLREDUCE_FN(allreduce)
+    emu().corrla_emu_set_comm(cb, world)
+
+    d = np.load(os.path.join(out_dir, "input.npz"))
+    a, omega = d["A"], d["omega"]
+    k, q, p = int(d["k"]), int(d["q"]), int(d["p"])
+    m = a.shape[0]
+    lo, hi = rank * m // world, (rank + 1) * m // world
+    for dtype in (np.float64, np.float32):
+        a_loc = np.ascontiguousarray(a[lo:hi].astype(dtype))
+        u, s, vt = emu_rsvd(a_loc, k, q, p, omega=omega.astype(dtype), sharded=True)
+        np.savez(os.path.join(out_dir, f"out_{np.dtype(dtype).name}_rank{rank}.npz"), u=u, s=s, vt=vt, lo=lo, hi=hi,
+                 n_allreduce=calls["n"])
+        calls["n"] = 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
