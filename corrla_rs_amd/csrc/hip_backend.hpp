@@ -74,6 +74,10 @@ class HipDev {
     set_lds_attrs<double>();
     set_jacobi_attrs<float>();
     set_jacobi_attrs<double>();
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_block_round_kernel<float>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_block_round_kernel<double>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     split_nn_override_ = env_int("CORRLA_SPLIT_NN", 0);
     split_tn_override_ = env_int("CORRLA_SPLIT_TN", 0);
     mw_override_ = env_int("CORRLA_MW", 0);
@@ -241,17 +245,70 @@ class HipDev {
                               stream));
     if (dst_is_host) sync();
   }
-  // SVD of the l x l core (random_svd.rs:89): device Jacobi when W fits in LDS, host Jacobi otherwise
+  // SVD of the l x l core (random_svd.rs:89).  Default: single-workgroup LDS-resident Jacobi when W fits
+  // in LDS, block Jacobi over many waves otherwise (any l up to 1024).  CORRLA_SVD=block / host force the
+  // block kernel / the f64 host Jacobi.
   template <class T>
   void small_svd(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev) {
-    constexpr size_t kLdsMax = (size_t)160 * 1024;
-    const size_t lds2 = k::jacobi_lds_bytes((int)l, sizeof(T), true);
-    const size_t lds1 = k::jacobi_lds_bytes((int)l, sizeof(T), false);
-    if (lds1 > kLdsMax || l > k::kJacobiMaxL || env_int("CORRLA_HOST_SVD", 0)) {
+    const char* mode = std::getenv("CORRLA_SVD");
+    const bool want_host = (mode && std::strcmp(mode, "host") == 0) || env_int("CORRLA_HOST_SVD", 0);
+    const bool want_lds = mode && std::strcmp(mode, "lds") == 0;
+    if (want_host || l > 1024) {
       small_svd_host(*this, c, l, k, m1, m2, s_dev);
       return;
     }
-    const int64_t ldv = round_up(l, 16);
+    const bool want_block = mode && std::strcmp(mode, "block") == 0;
+    (void)want_lds;
+    if (want_block) {
+      small_svd_block(c, l, k, m1, m2, s_dev);
+      return;
+    }
+    small_svd_lds(c, l, k, m1, m2, s_dev);  // falls through to the block kernel when W does not fit in LDS
+  }
+
+  template <class T>
+  void small_svd_block(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev) {
+    const int nb = (int)(2 * ((l + 15) / 16));          // even number of 8-column blocks
+    const int cols_pad = nb * 8;
+    const int rows_pad = (int)round_up(l, 16);
+    const int64_t ld = rows_pad;
+    T* wj = (T*)alloc_bytes((size_t)ld * cols_pad * sizeof(T));
+    T* vj = (T*)alloc_bytes((size_t)ld * cols_pad * sizeof(T));
+    k::JacobiCtl* ctl = (k::JacobiCtl*)alloc_bytes(sizeof(k::JacobiCtl));
+    hipLaunchKernelGGL((k::jacobi_init_kernel<T>), dim3(64), dim3(256), 0, stream, (const T*)c.p, c.ld, (int)l, wj, ld, vj,
+                       ld, cols_pad, rows_pad, ctl);
+    const double eps = (double)std::numeric_limits<T>::epsilon();
+    const float tol_early = (float)std::sqrt(eps);
+    const size_t lds = (size_t)(2 * 16 * (rows_pad + 1) + 3 * 16 * 17 + 32) * sizeof(T) + 16 * sizeof(int) + 64;
+    const int max_sweeps = env_int("CORRLA_JACOBI_SWEEPS", 12), inner = env_int("CORRLA_JACOBI_INNER", 1);
+    for (int sw = 0; sw < max_sweeps; ++sw) {
+      for (int round = 0; round < nb - 1; ++round)
+        hipLaunchKernelGGL((k::jacobi_block_round_kernel<T>), dim3(nb / 2), dim3(64), lds, stream, wj, ld, vj, ld, rows_pad,
+                           nb, round, inner, ctl);
+      hipLaunchKernelGGL(k::jacobi_sweep_end_kernel, dim3(1), dim3(1), 0, stream, ctl, tol_early);
+    }
+    const size_t lds_fin = (size_t)(l + 2) * sizeof(T) + (size_t)(l + 2) * sizeof(int) + 64;
+    hipLaunchKernelGGL((k::jacobi_finish_kernel<T>), dim3(1), dim3(1024), lds_fin, stream, (const T*)wj, ld, (const T*)vj,
+                       ld, (int)l, m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k);
+    CORRLA_HIP(hipGetLastError());
+    if (env_int("CORRLA_DEBUG", 0)) {
+      k::JacobiCtl h;
+      CORRLA_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
+      sync();
+      std::fprintf(stderr, "[corrla] block jacobi l=%d nb=%d sweeps=%u done=%u\n", (int)l, nb, h.sweeps, h.done);
+    }
+  }
+
+  template <class T>
+  void small_svd_lds(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev) {
+    constexpr size_t kLdsMax = (size_t)160 * 1024;
+    const size_t lds2 = k::jacobi_lds_bytes((int)l, sizeof(T), true);
+    const size_t lds1 = k::jacobi_lds_bytes((int)l, sizeof(T), false);
+    if (lds1 > kLdsMax || l > k::kJacobiMaxL) {
+      small_svd_block(c, l, k, m1, m2, s_dev);
+      return;
+    }
+    const int64_t ldv = round_up(k::jacobi_pitch((int)l, (int)(16 / sizeof(T))), 16);
     T* vg = (T*)alloc_bytes((size_t)ldv * l * sizeof(T));
     int* info = (int*)alloc_bytes(sizeof(int) * 4);
     const double eps = (double)std::numeric_limits<T>::epsilon();
@@ -262,14 +319,17 @@ class HipDev {
 #define CORRLA_JACOBI(VL, G, E)                                                                                      \
   hipLaunchKernelGGL((k::jacobi_svd_kernel<T, VL, G, E>), dim3(1), dim3(1024), lds, stream, (const T*)c.p, c.ld, (int)l, \
                      vg, ldv, m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, tol_early, 40, info)
-    if (l <= 128) {
-      if (v_lds) CORRLA_JACOBI(true, 16, 8); else CORRLA_JACOBI(false, 16, 8);
-    } else if (l <= 144 && sizeof(T) == 4) {
-      if (v_lds) CORRLA_JACOBI(true, 8, 18); else CORRLA_JACOBI(false, 8, 18);
-    } else if (l <= 144) {
-      if (v_lds) CORRLA_JACOBI(true, 16, 9); else CORRLA_JACOBI(false, 16, 9);
+    // chunks per column = pitch / VW; G lanes x E chunks per lane must cover them; npairs <= 1024 / G for one round
+    const int nchunk = k::jacobi_pitch((int)l, (int)(16 / sizeof(T))) / (int)(16 / sizeof(T));
+    if (l <= 128 && nchunk <= 32) {
+      if (v_lds) CORRLA_JACOBI(true, 16, 2); else CORRLA_JACOBI(false, 16, 2);
+    } else if (nchunk <= 40) {
+      if (v_lds) CORRLA_JACOBI(true, 8, 5); else CORRLA_JACOBI(false, 8, 5);
+    } else if (nchunk <= 72) {
+      if (v_lds) CORRLA_JACOBI(true, 8, 9); else CORRLA_JACOBI(false, 8, 9);
     } else {
-      if (v_lds) CORRLA_JACOBI(true, 16, 12); else CORRLA_JACOBI(false, 16, 12);
+      small_svd_block(c, l, k, m1, m2, s_dev);
+      return;
     }
 #undef CORRLA_JACOBI
     CORRLA_HIP(hipGetLastError());
@@ -384,14 +444,12 @@ class HipDev {
   static void set_jacobi_attrs() {
     const int lds = 160 * 1024;
     const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 16, 8>, attr, lds));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 16, 8>, attr, lds));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 8, 18>, attr, lds));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 8, 18>, attr, lds));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 16, 9>, attr, lds));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 16, 9>, attr, lds));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 16, 12>, attr, lds));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 16, 12>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 16, 2>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 16, 2>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 8, 5>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 8, 5>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, true, 8, 9>, attr, lds));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_kernel<T, false, 8, 9>, attr, lds));
   }
   template <class T>
   static void set_lds_attrs() {

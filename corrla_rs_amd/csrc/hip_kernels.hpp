@@ -543,9 +543,9 @@ __global__ void fill_normal_kernel(T* p, int64_t rows, int64_t cols, int64_t rs,
 // One-sided (Hestenes) Jacobi in ONE workgroup of 1024 threads: W = C lives in LDS (column-major,
 // odd pitch) and so does the accumulated right-rotation matrix V when both fit (else V sits in
 // global memory, L2-resident, same CU).  A round-robin tournament gives n/2 disjoint column pairs
-// per step; each pair is rotated by a G-lane group (G = 16: 64 pairs in flight; G = 8 (f32, up to
-// 128 pairs): the whole step in ONE round), lane gl owning elements gl + G*e, e < E, of the four
-// columns involved.
+// per step; each pair is rotated by a G-lane group (G = 16: 64 pairs in flight; G = 8: 128 pairs, the
+// whole step in ONE round), lane gl owning the 16-byte chunks gl + G*e, e < E, of the four columns
+// involved (ds_read_b128 / ds_write_b128: the scalar version was bound by LDS instruction issue).
 // They are loaded once with independent LDS reads, the three dot products are reduced by xor-
 // shuffles inside the group, and the rotation is applied in registers before the write-back.
 // Convergence is quadratic, so the sweep in which every |w_p.w_q| / (|w_p||w_q|) was already below
@@ -553,13 +553,25 @@ __global__ void fill_normal_kernel(T* p, int64_t rows, int64_t cols, int64_t rs,
 // C = U_c diag(sigma) V_c^T.  The kernel sorts sigma descending and writes sigma[:k], V_c[:, :k]
 // (-> m1) and U_c[:, :k] (-> m2) directly into the zero-padded skinny operands of the GEMMs that
 // follow (U = Q * m1, V = Qb * m2), so the final stage needs no host round trip.
+// column pitch of the LDS-resident Jacobi images: multiple of the 16-byte vector width, and an odd number
+// of 16-byte slots so consecutive columns start on different bank groups
+__host__ __device__ inline int jacobi_pitch(int l, int vw) {
+  int slots = (l + vw - 1) / vw;
+  slots |= 1;
+  return slots * vw;
+}
 template <class T, bool V_IN_LDS, int G, int E>
 __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ c, int64_t ldc, int l, T* vg, int64_t ldv,
                                                           T* m1, int64_t ld1, T* m2, int64_t ld2, T* s_out, int k, T tol,
                                                           T tol_early, int max_sweeps, int* info) {
+  typedef typename MT<T>::vec_t vec_t;
+  constexpr int VW = MT<T>::VEC;  // elements per 16-byte LDS access
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NG = 1024 / G;  // groups = pairs in flight
-  const int LP = l | 1;
+  // Column pitch: a multiple of the vector width (16-byte aligned columns); the pad rows stay zero, so
+  // whole 16-byte chunks are loaded, rotated and stored without per-element masks.
+  const int LP = jacobi_pitch(l, VW);
+  const int nchunk = LP / VW;
   T* w = (T*)smem;
   T* sigma = w + (size_t)l * LP * (V_IN_LDS ? 2 : 1);
   int* order = (int*)(sigma + l + 2);
@@ -569,9 +581,9 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
     ldv = LP;
   }
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < l * l; idx += 1024) {
-    const int j = idx / l, i = idx - j * l;
-    w[j * LP + i] = c[(int64_t)j * ldc + i];
+  for (int idx = tid; idx < l * LP; idx += 1024) {
+    const int j = idx / LP, i = idx - j * LP;
+    w[j * LP + i] = (i < l) ? c[(int64_t)j * ldc + i] : (T)0;
     vg[(int64_t)j * ldv + i] = (i == j) ? (T)1 : (T)0;
   }
   __syncthreads();
@@ -598,27 +610,32 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
           q = t_;
         }
         if (q >= l) continue;  // the dummy player (uniform within the group)
-        T* wp = w + p * LP;
-        T* wq = w + q * LP;
-        T* vp = vg + (int64_t)p * ldv;
-        T* vq = vg + (int64_t)q * ldv;
-        T x[E], y[E], vx[E], vy[E];
+        vec_t* wp = (vec_t*)(w + p * LP);
+        vec_t* wq = (vec_t*)(w + q * LP);
+        vec_t* vp = (vec_t*)(vg + (int64_t)p * ldv);
+        vec_t* vq = (vec_t*)(vg + (int64_t)q * ldv);
+        vec_t x[E], y[E], vx[E], vy[E];
+        vec_t zero;
+#pragma unroll
+        for (int z = 0; z < VW; ++z) zero[z] = (T)0;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          const int i = gl + G * e;
-          const bool in = i < l;
-          x[e] = in ? wp[i] : (T)0;
-          y[e] = in ? wq[i] : (T)0;
-          vx[e] = in ? vp[i] : (T)0;
-          vy[e] = in ? vq[i] : (T)0;
+          const int ch = gl + G * e;
+          const bool in = ch < nchunk;
+          x[e] = in ? wp[ch] : zero;
+          y[e] = in ? wq[ch] : zero;
+          vx[e] = in ? vp[ch] : zero;
+          vy[e] = in ? vq[ch] : zero;
         }
         T a = 0, b = 0, g = 0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          a += x[e] * x[e];
-          b += y[e] * y[e];
-          g += x[e] * y[e];
-        }
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+          for (int z = 0; z < VW; ++z) {
+            a += x[e][z] * x[e][z];
+            b += y[e][z] * y[e][z];
+            g += x[e][z] * y[e][z];
+          }
 #pragma unroll
         for (int msk = 1; msk < G; msk <<= 1) {
           a += __shfl_xor(a, msk, G);
@@ -634,12 +651,12 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
           const T sn = cs * t;
 #pragma unroll
           for (int e = 0; e < E; ++e) {
-            const int i = gl + G * e;
-            if (i < l) {
-              wp[i] = cs * x[e] - sn * y[e];
-              wq[i] = sn * x[e] + cs * y[e];
-              vp[i] = cs * vx[e] - sn * vy[e];
-              vq[i] = sn * vx[e] + cs * vy[e];
+            const int ch = gl + G * e;
+            if (ch < nchunk) {
+              wp[ch] = cs * x[e] - sn * y[e];
+              wq[ch] = sn * x[e] + cs * y[e];
+              vp[ch] = cs * vx[e] - sn * vy[e];
+              vq[ch] = sn * vx[e] + cs * vy[e];
             }
           }
           if (gl == 0) {
@@ -692,9 +709,246 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
   if (tid == 0) info[0] = sweep;
 }
 __host__ __device__ inline size_t jacobi_lds_bytes(int l, size_t esz, bool v_in_lds) {
-  return (size_t)l * (l | 1) * esz * (v_in_lds ? 2 : 1) + (size_t)(l + 2) * esz + (size_t)(l + 2) * sizeof(int) + 64;
+  const int vw = (int)(16 / esz);
+  return (size_t)l * jacobi_pitch(l, vw) * esz * (v_in_lds ? 2 : 1) + (size_t)(l + 2) * esz +
+         (size_t)(l + 2) * sizeof(int) + 64;
 }
-constexpr int kJacobiMaxL = 192;  // 16-lane groups x 12 elements per lane
+constexpr int kJacobiMaxL = 256;  // 8-lane groups x 8 chunks x 4 elements
+
+// ---- block Jacobi SVD of the l x l core for any l (random_svd.rs:89) -----------------------------
+// W (= C on entry) and V (= I) live in global memory (L2-resident, a few hundred KiB).  The columns are
+// cut into nb blocks of 8; a round-robin tournament over the blocks gives nb/2 disjoint block pairs per
+// round, one kernel launch per round, ONE WAVE per block pair:
+//   1. stage the 16 columns of W and V into LDS,
+//   2. G = W_S^T W_S (16 x 16) with MFMAs (the same LDS element feeds both operands),
+//   3. two-sided Jacobi on G in LDS (tournament of 8 disjoint rotations per step, all 64 lanes apply
+//      them) accumulating the 16 x 16 rotation J -- in exact arithmetic this is one-sided Jacobi on the
+//      16 columns without touching the long columns,
+//   4. W_S <- W_S J and V_S <- V_S J with MFMAs, stored straight from the accumulators.
+// Every element of W and V is read and written once per ROUND (2*nb/8 times fewer than per column-pair
+// step).  Convergence: each wave publishes max |g_pq| / sqrt(g_pp g_qq) of its block pair (before
+// rotating) with atomicMax; a one-thread kernel per sweep raises `done` when the whole sweep stayed
+// below tol_early (quadratic convergence), and every later launch returns immediately.
+struct JacobiCtl {
+  unsigned done;
+  unsigned max_bits;  // float bits of the sweep's max relative off-diagonal (non-negative floats order as uints)
+  unsigned sweeps;
+  unsigned pad;
+};
+
+template <class T>
+__global__ __launch_bounds__(64) void jacobi_block_round_kernel(T* w, int64_t ldw, T* v, int64_t ldv, int rows_pad, int nb,
+                                                                int round, int inner_sweeps, JacobiCtl* ctl) {
+  typedef typename MT<T>::acc_t acc_t;
+  if (ctl->done) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int LP = rows_pad + 1;
+  T* wt = (T*)smem;          // [16][LP]
+  T* vt = wt + 16 * LP;      // [16][LP]
+  T* gm = vt + 16 * LP;      // [16][17]
+  T* g2 = gm + 16 * 17;      // [16][17]
+  T* jm = g2 + 16 * 17;      // [16][17]
+  T* alpha = jm + 16 * 17;   // [16]
+  T* beta = alpha + 16;      // [16]
+  int* part = (int*)(beta + 16);
+  const int lane = threadIdx.x;
+  const int x = lane & 15, kq = lane >> 4;
+  // block pair of this workgroup
+  int bi, bj;
+  {
+    const int pr = blockIdx.x, n = nb;
+    if (pr == 0) {
+      bi = n - 1;
+      bj = round;
+    } else {
+      bi = (round + pr) % (n - 1);
+      bj = (round - pr + (n - 1)) % (n - 1);
+    }
+    if (bi > bj) {
+      const int t_ = bi;
+      bi = bj;
+      bj = t_;
+    }
+  }
+  auto gcol = [&](int c) { return (c < 8) ? bi * 8 + c : bj * 8 + (c - 8); };
+  // 1. stage
+  for (int e = lane; e < 16 * rows_pad; e += 64) {
+    const int c = e / rows_pad, r = e - c * rows_pad;
+    const int64_t gc = gcol(c);
+    wt[c * LP + r] = w[gc * ldw + r];
+    vt[c * LP + r] = v[gc * ldv + r];
+  }
+  __syncthreads();
+  // 2. Gram
+  acc_t acc = (acc_t){0, 0, 0, 0};
+  for (int it = 0; it < rows_pad / 16; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const T a = wt[x * LP + 16 * it + 4 * kq + j];
+      acc = MT<T>::mma(a, a, acc);
+    }
+  }
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int r = MT<T>::drow(lane, jj);
+    gm[r * 17 + x] = acc[jj];
+    jm[r * 17 + x] = (r == x) ? (T)1 : (T)0;
+  }
+  __syncthreads();
+  // convergence measure of this block pair
+  {
+    float mx = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int r = MT<T>::drow(lane, jj);
+      if (r != x) {
+        const T d = gm[r * 17 + r] * gm[x * 17 + x];
+        if (d > (T)0) mx = fmaxf(mx, (float)(fabs(gm[r * 17 + x]) / sqrt(d)));
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    if (lane == 0) atomicMax(&ctl->max_bits, __float_as_uint(mx));
+  }
+  // 3. two-sided Jacobi on G, accumulating J
+  const T tiny = (T)4 * (T)(sizeof(T) == 4 ? 1.1920929e-07 : 2.220446049250313e-16);
+  for (int sw = 0; sw < inner_sweeps; ++sw) {
+    for (int step = 0; step < 15; ++step) {
+      if (lane < 8) {
+        int p, q;
+        if (lane == 0) {
+          p = 15;
+          q = step;
+        } else {
+          p = (step + lane) % 15;
+          q = (step - lane + 15) % 15;
+        }
+        if (p > q) {
+          const int t_ = p;
+          p = q;
+          q = t_;
+        }
+        const T a = gm[p * 17 + p], b = gm[q * 17 + q], g = gm[p * 17 + q];
+        T cs = (T)1, sn = (T)0;
+        const T ab = sqrt(a * b);
+        if (ab > (T)0 && fabs(g) > tiny * ab) {
+          const T zeta = (b - a) / ((T)2 * g);
+          const T t = (zeta >= (T)0 ? (T)1 : (T)-1) / (fabs(zeta) + sqrt((T)1 + zeta * zeta));
+          cs = (T)1 / sqrt((T)1 + t * t);
+          sn = cs * t;
+        }
+        alpha[p] = cs;
+        beta[p] = -sn;
+        part[p] = q;
+        alpha[q] = cs;
+        beta[q] = sn;
+        part[q] = p;
+      }
+      __syncthreads();
+      // column pass: G2 = G R, J <- J R
+      T jn[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = lane + 64 * e, r = idx >> 4, cx = idx & 15, pc = part[cx];
+        g2[r * 17 + cx] = alpha[cx] * gm[r * 17 + cx] + beta[cx] * gm[r * 17 + pc];
+        jn[e] = alpha[cx] * jm[r * 17 + cx] + beta[cx] * jm[r * 17 + pc];
+      }
+      __syncthreads();
+      // row pass: G = R^T G2
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = lane + 64 * e, r = idx >> 4, cx = idx & 15, pr_ = part[r];
+        gm[r * 17 + cx] = alpha[r] * g2[r * 17 + cx] + beta[r] * g2[pr_ * 17 + cx];
+        jm[r * 17 + cx] = jn[e];
+      }
+      __syncthreads();
+    }
+  }
+  // 4. apply J to the W and V column blocks
+  T jb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) jb[ks] = jm[(4 * ks + kq) * 17 + x];
+  const int64_t gx = gcol(x);
+  for (int it = 0; it < rows_pad / 16; ++it) {
+    acc_t aw = (acc_t){0, 0, 0, 0}, av = (acc_t){0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      aw = MT<T>::mma(wt[(4 * ks + kq) * LP + 16 * it + x], jb[ks], aw);
+      av = MT<T>::mma(vt[(4 * ks + kq) * LP + 16 * it + x], jb[ks], av);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int r = 16 * it + MT<T>::drow(lane, jj);
+      w[gx * ldw + r] = aw[jj];
+      v[gx * ldv + r] = av[jj];
+    }
+  }
+}
+
+__global__ void jacobi_sweep_end_kernel(JacobiCtl* ctl, float tol_early) {
+  if (ctl->done) return;
+  ctl->sweeps += 1;
+  if (__uint_as_float(ctl->max_bits) <= tol_early) ctl->done = 1;
+  ctl->max_bits = 0;
+}
+
+template <class T>
+__global__ void jacobi_init_kernel(const T* c, int64_t ldc, int l, T* w, int64_t ldw, T* v, int64_t ldv, int cols_pad,
+                                   int rows_pad, JacobiCtl* ctl) {
+  const int64_t total = (int64_t)cols_pad * rows_pad;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e / rows_pad), i = (int)(e - (int64_t)j * rows_pad);
+    const bool in = i < l && j < l;
+    w[(int64_t)j * ldw + i] = in ? c[(int64_t)j * ldc + i] : (T)0;
+    v[(int64_t)j * ldv + i] = (in && i == j) ? (T)1 : (T)0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ctl->done = 0;
+    ctl->max_bits = 0;
+    ctl->sweeps = 0;
+    ctl->pad = 0;
+  }
+}
+
+// sigma_j = ||w_j||, descending order, outputs (see jacobi_svd_kernel)
+template <class T>
+__global__ __launch_bounds__(1024) void jacobi_finish_kernel(const T* w, int64_t ldw, const T* v, int64_t ldv, int l, T* m1,
+                                                             int64_t ld1, T* m2, int64_t ld2, T* s_out, int k) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sigma = (T*)smem;
+  int* order = (int*)(sigma + l + 2);
+  const int tid = threadIdx.x, group = tid >> 4, gl = tid & 15;
+  for (int j = group; j < l; j += 64) {
+    T a = 0;
+    for (int i = gl; i < l; i += 16) {
+      const T xx = w[(int64_t)j * ldw + i];
+      a += xx * xx;
+    }
+#pragma unroll
+    for (int msk = 1; msk < 16; msk <<= 1) a += __shfl_xor(a, msk, 16);
+    if (gl == 0) sigma[j] = sqrt(a);
+  }
+  __syncthreads();
+  for (int j = tid; j < l; j += 1024) {
+    const T sj = sigma[j];
+    int r = 0;
+    for (int i = 0; i < l; ++i) {
+      const T si = sigma[i];
+      r += (si > sj || (si == sj && i < j)) ? 1 : 0;
+    }
+    order[r] = j;
+  }
+  __syncthreads();
+  for (int r = group; r < k; r += 64) {
+    const int j = order[r];
+    const T sj = sigma[j];
+    const T inv = sj > (T)0 ? (T)1 / sj : (T)0;
+    for (int i = gl; i < l; i += 16) {
+      m2[(int64_t)r * ld2 + i] = w[(int64_t)j * ldw + i] * inv;
+      m1[(int64_t)r * ld1 + i] = v[(int64_t)j * ldv + i];
+    }
+    if (gl == 0) s_out[r] = sj;
+  }
+}
 
 // ---- layout helpers --------------------------------------------------------------------------
 // dst[r * ldd + c] = src[r * rs + c * cs]   (repack any strided matrix to padded row-major)
