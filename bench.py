@@ -26,7 +26,12 @@ sys.path.insert(0, ROOT)
 M_PER_GPU, N_COLS, RANK, N_ITER, N_OVER = 16384, 16384, 128, 2, 10
 SEED_A, SEED_OMEGA = 20241008, 1
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak
-CPU_SAMPLE = 8192              # cpu_baseline runs the oracle on a CPU_SAMPLE^2 corner of the same workload
+CPU_SAMPLE = 16384             # cpu_baseline runs the oracle on the CPU_SAMPLE^2 corner (= the whole matrix)
+CPU_THREADS = 16               # a 1-GPU box's CPU share; OpenBLAS is pinned to this many threads
+# HBM bytes per sketch launch from rocprofv3 PMC passes on this kernel/config (not collected live):
+# FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, separate --pmc runs
+TRAFFIC_BYTES_PER_LAUNCH = 1.150e9 + 22.7e6
+TRAFFIC_SOURCE = "profiles/r01_pmc_sketch_gemm_summary.txt"
 
 
 def log(*a):
@@ -37,24 +42,28 @@ def cpu_baseline(a_dev, l):
     """Reference CPU path beside the GPU number: the oracle (numpy restatement of random_svd.rs) on the
     GPU box's host cores, bounded sample, all cores (numpy/OpenBLAS threading)."""
     import numpy as np
+    from threadpoolctl import threadpool_limits
     from oracle import rsvd_oracle as orc
-    s = CPU_SAMPLE
+    s = min(CPU_SAMPLE, a_dev.shape[0], a_dev.shape[1])
     a = a_dev[:s, :s].contiguous().cpu().numpy()
     rng = np.random.default_rng(SEED_OMEGA)
     omega = rng.standard_normal((s, l)).astype(np.float32)
-    orc.random_svd(a[:1024, :1024], RANK, N_ITER, N_OVER, omega=omega[:1024])  # warm the BLAS threads
-    t0 = time.perf_counter()
-    orc.random_svd(a, RANK, N_ITER, N_OVER, omega=omega)
-    dt = time.perf_counter() - t0
-    flops = orc.algorithmic_flops(s, s, RANK, N_ITER, N_OVER)
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    return {"value": round(flops / dt / 1e9, 2), "unit": "GFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/rsvd_oracle.py random_svd on the {s}x{s} f32 corner of the same matrix, rank {RANK}, "
-                      f"q={N_ITER}, p={N_OVER}, {dt:.2f} s, numpy/OpenBLAS threads"}
+    threads = min(CPU_THREADS, avail)
+    with threadpool_limits(limits=threads):
+        orc.random_svd(a[:1024, :1024], RANK, N_ITER, N_OVER, omega=omega[:1024])  # warm the BLAS threads
+        t0 = time.perf_counter()
+        orc.random_svd(a, RANK, N_ITER, N_OVER, omega=omega)
+        dt = time.perf_counter() - t0
+    flops = orc.algorithmic_flops(s, s, RANK, N_ITER, N_OVER)
+    return {"value": round(flops / dt / 1e9, 2), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/rsvd_oracle.py random_svd (numpy restatement of random_svd.rs:15-110) on the {s}x{s} f32 "
+                      f"matrix of the same workload, rank {RANK}, q={N_ITER}, p={N_OVER}: {dt:.2f} s on {threads} "
+                      f"OpenBLAS threads ({avail} logical CPUs visible)"}
 
 
 def main():
@@ -74,14 +83,18 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     dist = None
-    if world > 1:
+    # CORRLA_BENCH_FORCE_SHARDED=1: exercise the process-group + RCCL + row-sharded entry point at any
+    # world size (used to rehearse the N > 1 code path on a 1-GPU box)
+    force_sharded = os.environ.get("CORRLA_BENCH_FORCE_SHARDED", "0") == "1"
+    use_dist = world > 1 or force_sharded
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     ctx = cr.Context(local_rank)
-    if world > 1:
+    if use_dist:
         ids = [cr.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(ids[0], rank, world)
@@ -94,13 +107,13 @@ def main():
     flops = cr.algorithmic_flops(m_glob, n, k, q, p)
 
     def step():
-        if world > 1:
+        if use_dist:
             return ctx.rsvd_sharded(a, k, q, p, seed=SEED_OMEGA)
         return ctx.rsvd(a, k, q, p, seed=SEED_OMEGA)
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -112,7 +125,7 @@ def main():
         out = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -132,8 +145,10 @@ def main():
         sk_flops = 2.0 * m_loc * n * l   # algorithmic: unpadded l = 138 (the kernel computes 144 columns)
         achieved = sk_flops / (sk_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": "gemm_nn_kernel<float,9> (sketch Y = A*Omega, 16384x16384x138)",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                    "traffic_unit": "bytes per launch (algorithmic: 1.074e9 A + 9.4e6 Omega + 1.9e7 out)",
+                    "traffic_source": TRAFFIC_SOURCE + " (rocprofv3 --pmc, separate passes; not collected live)",
+                    "kernel": "gemm_nn_kernel<float,2,9> + slab_reduce (sketch Y = A*Omega, 16384x16384x138)",
                     "avg_launch_ms": round(sk_ms, 4),
                     "hbm_GBps_on_A_read": round(m_loc * n * 4 / (sk_ms * 1e-3) / 1e9, 1)}
         log(f"[bench] step {ms_per_step:.3f} ms  value {value:.0f} GFLOP/s  sketch {sk_ms:.3f} ms = {achieved:.1f} TF "
@@ -161,7 +176,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
