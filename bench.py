@@ -120,9 +120,13 @@ def main():
     for _ in range(args.warmup):
         out = step()
     fence()
+    sketch_ms_in_steps = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+        # device time of this step's sketch GEMM: hipEvents the library recorded on its own stream around the
+        # launch; reading them back costs no GPU work and no extra synchronisation (the call has completed)
+        sketch_ms_in_steps.append(ctx.timings()["sketch_kernel_ms"])
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -141,7 +145,12 @@ def main():
         # dominant kernel: the sketch GEMM Y = A * Omega (random_svd.rs:31), hipEvents on the library's stream
         om = torch.empty((n, l), dtype=torch.float32, device=dev)
         ctx.fill_normal(om, seed=SEED_OMEGA)
-        sk_ms, _ = ctx.time_sketch(a, om, reps=20)
+        # (a) the judged number: average duration of the sketch launch INSIDE the K timed steps
+        sk_ms = sum(sketch_ms_in_steps) / len(sketch_ms_in_steps)
+        # (b) for information: the same launch back-to-back after the chip's clocks have ramped up (the first
+        #     ~25 ms of sustained load run ~15 % slower on MI355X; profiles/r01_dvfs_ramp.txt)
+        ctx.time_sketch(a, om, reps=60)
+        sk_warm_ms, _ = ctx.time_sketch(a, om, reps=40)
         sk_flops = 2.0 * m_loc * n * l   # algorithmic: unpadded l = 138 (the kernel computes 144 columns)
         achieved = sk_flops / (sk_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -150,9 +159,15 @@ def main():
                     "traffic_source": TRAFFIC_SOURCE + " (rocprofv3 --pmc, separate passes; not collected live)",
                     "kernel": "gemm_nn_kernel<float,2,9> + slab_reduce (sketch Y = A*Omega, 16384x16384x138)",
                     "avg_launch_ms": round(sk_ms, 4),
+                    "measured": "hipEvents on the library's stream around the sketch launch of each timed step",
+                    "steady_state": {"avg_launch_ms": round(sk_warm_ms, 4),
+                                     "achieved": round(sk_flops / (sk_warm_ms * 1e-3) / 1e12, 2),
+                                     "frac": round(sk_flops / (sk_warm_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                     "note": "same launch back-to-back after >= 60 warm launches (clock ramp)"},
                     "hbm_GBps_on_A_read": round(m_loc * n * 4 / (sk_ms * 1e-3) / 1e9, 1)}
-        log(f"[bench] step {ms_per_step:.3f} ms  value {value:.0f} GFLOP/s  sketch {sk_ms:.3f} ms = {achieved:.1f} TF "
-            f"({100 * achieved / PEAK_F32_MFMA_TFLOPS:.1f}% of f32 MFMA peak)")
+        log(f"[bench] step {ms_per_step:.3f} ms  value {value:.0f} GFLOP/s  sketch in-step {sk_ms:.3f} ms = {achieved:.1f} TF "
+            f"({100 * achieved / PEAK_F32_MFMA_TFLOPS:.1f}% of f32 MFMA peak); warmed-up {sk_warm_ms:.3f} ms = "
+            f"{sk_flops / (sk_warm_ms * 1e-3) / 1e12:.1f} TF")
         log(f"[bench] last-call phases (ms): {json.dumps({k_: round(v, 3) if isinstance(v, float) else v for k_, v in tm.items()})}")
         eye = torch.eye(k, dtype=torch.float64, device=dev)
         vo = (vt.double() @ vt.double().t() - eye).abs().max().item()

@@ -20,7 +20,8 @@ class Opts(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("total_ms", dbl), ("sketch_ms", dbl), ("power_ms", dbl), ("qr_ms", dbl), ("project_ms", dbl),
-                ("small_svd_ms", dbl), ("finalize_ms", dbl), ("qr_passes", i32), ("reserved", i32)]
+                ("small_svd_ms", dbl), ("finalize_ms", dbl), ("qr_passes", i32), ("reserved", i32),
+                ("sketch_kernel_ms", dbl)]
 
 
 # symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header

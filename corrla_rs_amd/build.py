@@ -41,6 +41,7 @@ def build_product(force=False, verbose=False):
         raise RuntimeError("hipcc not found: cannot build libcorrla_rsvd.so")
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma",  # host-side l x l factorizations (small_linalg.hpp)
            "-I" + os.path.join(ROOT, "include"), os.path.join(CSRC, "corrla_rsvd.hip"),
            "-o", LIB_PATH, "-L" + os.path.join(ROCM, "lib"), "-lrccl",
            "-Wl,-rpath," + os.path.join(ROCM, "lib")]

@@ -158,6 +158,7 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
   }
   dev.copy_values_out(s_dev, k, s, host_ptrs);
   dev.end_call();
+  drv.tm.sketch_kernel_ms = dev.event_elapsed_ms(0, 1);
   if (tm_out) *tm_out = drv.tm;
 }
 

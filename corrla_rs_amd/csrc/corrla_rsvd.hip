@@ -31,6 +31,9 @@ corrla_status rsvd_c(corrla_ctx* ctx, bool host, bool sharded, const T* a, int64
     std::lock_guard<std::mutex> lk(c->mu);
     rsvd_entry<HipDev, T>(c->dev, host, sharded, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt, &c->last,
                           c->profile);
+    if (c->profile && env_int("CORRLA_DEBUG", 0))
+      std::fprintf(stderr, "[corrla] qr breakdown (ms): gram %.3f  download+check %.3f  host chol/inv %.3f  upload+apply %.3f  (%d passes)\n",
+                   c->last.qr_gram_ms, c->last.qr_down_ms, c->last.qr_host_ms, c->last.qr_apply_ms, c->last.qr_passes);
   });
 }
 template <class T>
@@ -124,6 +127,7 @@ CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings*
     out->finalize_ms = t.finalize_ms;
     out->qr_passes = t.qr_passes;
     out->reserved = 0;
+    out->sketch_kernel_ms = t.sketch_kernel_ms;
   });
 }
 

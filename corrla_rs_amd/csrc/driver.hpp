@@ -96,6 +96,11 @@ struct RunOpts {
 struct Timings {
   double total_ms = 0, sketch_ms = 0, power_ms = 0, qr_ms = 0, project_ms = 0, small_svd_ms = 0, finalize_ms = 0;
   int qr_passes = 0;
+  // breakdown of qr_ms (only filled when phase profiling is on): Gram GEMM, D2H + analysis, host Cholesky /
+  // inverse, H2D + apply GEMM
+  double qr_gram_ms = 0, qr_down_ms = 0, qr_host_ms = 0, qr_apply_ms = 0;
+  // device time of the sketch GEMM Y = A*Omega of this call (events on the compute stream; no extra sync)
+  double sketch_kernel_ms = 0;
 };
 
 struct PhaseTimer {
@@ -147,7 +152,9 @@ struct RsvdDriver {
   // rest of the pipeline represents "arbitrary completion" directions of a rank-deficient QR
   // (their singular values are 0 either way; random_svd.rs:153-196 exercises this).
   // Returns the number of non-zero (orthonormal) columns.
-  int64_t orthonormalize(Skinny<T>& y, Skinny<T>& tmp, bool sharded) {
+  // `rough`: stop after the first clean Cholesky pass -- enough for the in-loop re-orthonormalisations
+  // (random_svd.rs:37-39), whose only role is to keep the sketch well conditioned; the span is unchanged.
+  int64_t orthonormalize(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough = false) {
     const int64_t l = y.cols;
     int64_t r = l;
     const double eps = (double)std::numeric_limits<T>::epsilon();
@@ -155,16 +162,33 @@ struct RsvdDriver {
     Skinny<T> gd = dev.template alloc_skinny<T>(l, l);
     Skinny<T> md = dev.template alloc_skinny<T>(l, l);
     int fails = 0;
+    // After a clean Cholesky pass whose pivots predict ||Y1^T Y1 - I|| = E small, the polishing pass needs
+    // no host: (I + E)^(-1/2) = I - E/2 + 3E^2/8 - 5E^3/16 + O(E^4) is formed on the device.
+    bool series_next = false;
+    const double series_max_e = sizeof(T) == 4 ? 1e-2 : 1e-4;  // O(E^4) stays below eps
     for (int pass = 0; pass < 12; ++pass) {
       if (r == 0) break;
       // G (r x r) = Y[:, :r]^T Y[:, :r]
       Skinny<T> yv = y.view_cols(r);
       Skinny<T> gv = gd.view_cols(r);
       gv.rows = r;
+      PhaseTimer qt;
       dev.gemm_nn(as_rowmajor_transposed(y, r), yv, gv, kNone);
       if (sharded) dev.allreduce(gd.p, (size_t)gd.ld * (size_t)gd.cols_alloc);
-      dev.download_skinny(gv, r, r, g.data());
+      phase(tm.qr_gram_ms, qt);
       ++tm.qr_passes;
+      if (series_next) {
+        Skinny<T> mv = md.view_cols(r);
+        mv.rows = r;
+        dev.inv_sqrt_series(gv, r, mv);
+        Skinny<T> out = tmp.view_cols(r);
+        dev.gemm_tn(as_rowmajor_transposed(y, r), mv, out, kNone);
+        if (r < l) dev.zero_cols(tmp, r, l);
+        std::swap(y.p, tmp.p);
+        phase(tm.qr_apply_ms, qt);
+        break;
+      }
+      dev.download_skinny(gv, r, r, g.data());
       double gmax = 0.0, dev_i = 0.0;
       for (int64_t j = 0; j < r; ++j)
         for (int64_t i = 0; i < r; ++i) {
@@ -177,10 +201,12 @@ struct RsvdDriver {
         r = 0;
         break;
       }
+      tm.qr_down_ms += qt.lap();
       if (dev_i <= 16.0 * eps) break;  // already orthonormal at working precision
       const bool near_i = dev_i <= 0.25;
       int64_t r_new = r;
       bool clean = false;
+      double min_ratio_last = 0.0;
       if (fails >= 3) {
         // exact-null directions: drop them.  G = V diag(lam) V^T (Jacobi on the symmetric G).
         uu.resize((size_t)r * r);
@@ -200,6 +226,7 @@ struct RsvdDriver {
         std::vector<double> rr(g.begin(), g.begin() + (size_t)r * r);
         double min_ratio = 0.0;
         clean = small::chol_upper((int)r, rr.data(), (int)r, 4.0 * eps, &min_ratio);
+        min_ratio_last = min_ratio;
         if (!clean) {
           ++fails;
           double shift = 16.0 * eps * gmax;
@@ -216,6 +243,7 @@ struct RsvdDriver {
         small::triu_inverse((int)r, rr.data(), (int)r);
         std::copy(rr.begin(), rr.end(), mm.begin());
       }
+      tm.qr_host_ms += qt.lap();
       // Y[:, :r_new] <- Y[:, :r] * M (r x r_new); columns >= r_new become zero.
       Skinny<T> mv = md.view_cols(r_new);
       mv.rows = r;
@@ -225,7 +253,11 @@ struct RsvdDriver {
       if (r_new < l) dev.zero_cols(tmp, r_new, l);
       std::swap(y.p, tmp.p);
       r = r_new;
-      if (clean && near_i) break;
+      phase(tm.qr_apply_ms, qt);
+      if (clean && (near_i || rough)) break;
+      // predicted orthogonality defect of the pass just applied: ~ l * eps * kappa^2 <= l * eps / min pivot ratio
+      if (clean && fails == 0 && r == l && 4.0 * (double)l * eps / std::max(min_ratio_last, 1e-300) <= series_max_e)
+        series_next = true;
     }
     return r;
   }
@@ -247,14 +279,16 @@ struct RsvdDriver {
     Skinny<T> z = dev.template alloc_skinny<T>(a.nt, l);
     double* ss_dev = dev.alloc_f64(1);
     T* inv_dev = dev.template alloc_scalar<T>(1);
+    dev.event_mark(0);
     a_times(a, om, y, kNone);  // :31
+    dev.event_mark(1);
     phase(tm.sketch_ms, pt);
     const T* scale = nullptr;
     for (int64_t i = 0; i < n_iter; ++i) {  // :35
       if (i > 2) {                          // :37-39
         if (scale) dev.scale_inplace(y, scale);
         phase(tm.power_ms, pt);
-        orthonormalize(y, y2, o.sharded);
+        orthonormalize(y, y2, o.sharded, /*rough=*/true);
         phase(tm.qr_ms, pt);
         scale = nullptr;
       }

@@ -69,6 +69,8 @@ class HipDev {
     num_cus = prop.multiProcessorCount;
     CORRLA_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     CORRLA_HIP(hipMalloc(&zero_page_, 256));
+    CORRLA_HIP(hipHostMalloc(&pinned_, kPinnedBytes, hipHostMallocDefault));
+    for (auto& e : events_) CORRLA_HIP(hipEventCreate(&e));
     CORRLA_HIP(hipMemsetAsync(zero_page_, 0, 256, stream));
     set_lds_attrs<float>();
     set_lds_attrs<double>();
@@ -81,6 +83,7 @@ class HipDev {
     split_nn_override_ = env_int("CORRLA_SPLIT_NN", 0);
     split_tn_override_ = env_int("CORRLA_SPLIT_TN", 0);
     mw_override_ = env_int("CORRLA_MW", 0);
+    gemm_debug_flags_ = env_int("CORRLA_GEMM_DEBUG", 0);  // timing-only ablations, results are wrong
   }
   ~HipDev() {
     (void)hipSetDevice(device);
@@ -88,6 +91,9 @@ class HipDev {
     if (comm) (void)ncclCommDestroy(comm);
     for (auto& c : chunks_) (void)hipFree(c.p);
     if (zero_page_) (void)hipFree(zero_page_);
+    if (pinned_) (void)hipHostFree(pinned_);
+    for (auto& e : events_)
+      if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
   HipDev(const HipDev&) = delete;
@@ -112,6 +118,7 @@ class HipDev {
   // ---- memory ----------------------------------------------------------------------------
   void begin_call() {
     CORRLA_HIP(hipSetDevice(device));
+    events_set_[0] = events_set_[1] = false;
     for (auto& c : chunks_) c.used = 0;
   }
   void end_call() { sync(); }
@@ -197,21 +204,35 @@ class HipDev {
   // device skinny (rows x cols leading block) -> host f64 column-major (ld = rows); synchronises
   template <class T>
   void download_skinny(const Skinny<T>& s, int64_t rows, int64_t cols, double* host) {
-    std::vector<T> tmp((size_t)rows * cols);
-    CORRLA_HIP(hipMemcpy2DAsync(tmp.data(), (size_t)rows * sizeof(T), s.p, (size_t)s.ld * sizeof(T),
-                                (size_t)rows * sizeof(T), (size_t)cols, hipMemcpyDeviceToHost, stream));
+    const size_t n = (size_t)rows * cols;
+    std::vector<T> heap;
+    T* tmp = (T*)pinned_;
+    if (n * sizeof(T) > kPinnedBytes) {
+      heap.resize(n);
+      tmp = heap.data();
+    }
+    CORRLA_HIP(hipMemcpy2DAsync(tmp, (size_t)rows * sizeof(T), s.p, (size_t)s.ld * sizeof(T), (size_t)rows * sizeof(T),
+                                (size_t)cols, hipMemcpyDeviceToHost, stream));
     sync();
-    for (size_t i = 0; i < tmp.size(); ++i) host[i] = (double)tmp[i];
+    for (size_t i = 0; i < n; ++i) host[i] = (double)tmp[i];
   }
   // host f64 column-major (rows x cols, ld_host) -> device skinny; the whole allocation is
   // rewritten so padding stays zero
   template <class T>
   void upload_skinny(const double* host, int64_t rows, int64_t cols, int64_t ld_host, Skinny<T>& dst) {
-    std::vector<T> tmp((size_t)dst.ld * dst.cols_alloc, (T)0);
+    const size_t n = (size_t)dst.ld * dst.cols_alloc;
+    std::vector<T> heap;
+    T* tmp = (T*)pinned_;
+    if (n * sizeof(T) > kPinnedBytes) {
+      heap.resize(n);
+      tmp = heap.data();
+    }
+    sync();  // the staging buffer may still feed an earlier copy
+    std::memset(tmp, 0, n * sizeof(T));
     for (int64_t j = 0; j < cols; ++j)
       for (int64_t i = 0; i < rows; ++i) tmp[(size_t)j * dst.ld + i] = (T)host[(size_t)j * ld_host + i];
-    CORRLA_HIP(hipMemcpyAsync(dst.p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, stream));
-    sync();
+    CORRLA_HIP(hipMemcpyAsync(dst.p, tmp, n * sizeof(T), hipMemcpyHostToDevice, stream));
+    if (!heap.empty()) sync();
   }
   template <class T>
   void upload_skinny_native(const T* host, int64_t ld_host, Skinny<T>& dst) {
@@ -245,6 +266,29 @@ class HipDev {
                               stream));
     if (dst_is_host) sync();
   }
+  // m_out (r x r) = (I + E)^(-1/2) with G = I + E given in g (overwritten by E); everything on the device
+  template <class T>
+  void inv_sqrt_series(Skinny<T>& g, int64_t r, Skinny<T>& m_out) {
+    Skinny<T> e2 = alloc_skinny<T>(r, r), e3 = alloc_skinny<T>(r, r);
+    if (e2.ld != g.ld || m_out.ld != g.ld) throw Error(ST_EINVAL, "internal: series operands must share a leading dimension");
+    dim3 grid((unsigned)((r + 63) / 64), (unsigned)r);
+    hipLaunchKernelGGL((k::series_prep_kernel<T>), grid, dim3(64), 0, stream, g.p, g.ld, (int)r);
+    Big<T> eb;  // E is symmetric: its column-major image is also its row-major image
+    eb.p = g.p;
+    eb.rows = r;
+    eb.cols = r;
+    eb.ld = g.ld;
+    eb.cols_readable = g.ld;
+    Skinny<T> gv = g.view_cols(r);
+    gv.rows = r;
+    gemm_nn(eb, gv, e2, (const T*)nullptr);
+    gemm_nn(eb, e2, e3, (const T*)nullptr);
+    memset_zero(m_out.p, (size_t)m_out.ld * m_out.cols_alloc * sizeof(T));
+    hipLaunchKernelGGL((k::series_combine_kernel<T>), grid, dim3(64), 0, stream, (const T*)g.p, (const T*)e2.p,
+                       (const T*)e3.p, g.ld, (int)r, m_out.p, m_out.ld);
+    CORRLA_HIP(hipGetLastError());
+  }
+
   // SVD of the l x l core (random_svd.rs:89).  Default: single-workgroup LDS-resident Jacobi when W fits
   // in LDS, block Jacobi over many waves otherwise (any l up to 1024).  CORRLA_SVD=block / host force the
   // block kernel / the f64 host Jacobi.
@@ -401,6 +445,21 @@ class HipDev {
     CORRLA_HIP(hipGetLastError());
   }
 
+  // hipEvents on the compute stream around a kernel sequence of the current call (read after end_call)
+  void event_mark(int i) {
+    CORRLA_HIP(hipEventRecord(events_[i], stream));
+    events_set_[i] = true;
+  }
+  double event_elapsed_ms(int i, int j) {
+    if (!events_set_[i] || !events_set_[j]) return 0.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, events_[i], events_[j]) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0.0;
+    }
+    return (double)ms;
+  }
+
   // hipEvent timing of `reps` back-to-back sketch products on this stream
   template <class F>
   double time_on_stream(int reps, F&& f) {
@@ -426,7 +485,11 @@ class HipDev {
   };
   std::vector<Chunk> chunks_;
   void* zero_page_ = nullptr;
-  int split_nn_override_ = 0, split_tn_override_ = 0, mw_override_ = 0;
+  void* pinned_ = nullptr;  // staging for the small l x l transfers
+  hipEvent_t events_[2] = {nullptr, nullptr};
+  bool events_set_[2] = {false, false};
+  static constexpr size_t kPinnedBytes = (size_t)8 << 20;
+  int split_nn_override_ = 0, split_tn_override_ = 0, mw_override_ = 0, gemm_debug_flags_ = 0;
 
   static void check_grid(const dim3& g) {
     if (g.y > 65535u || g.z > 65535u) throw Error(ST_EINVAL, "problem too large for the launch grid");
@@ -490,10 +553,11 @@ class HipDev {
   template <class T, int MW, int NT>
   void launch_one(bool tn, dim3 grid, const k::GemmArgs<T>& a) {
     const int lds = k::gemm_lds_bytes(MW, NT);
+    const dim3 block(64 * (4 + k::kLoaders));  // 4 MFMA waves + loader wave(s)
     if (tn)
-      hipLaunchKernelGGL((k::gemm_tn_kernel<T, MW, NT>), grid, dim3(256), lds, stream, a);
+      hipLaunchKernelGGL((k::gemm_tn_kernel<T, MW, NT>), grid, block, lds, stream, a);
     else
-      hipLaunchKernelGGL((k::gemm_nn_kernel<T, MW, NT>), grid, dim3(256), lds, stream, a);
+      hipLaunchKernelGGL((k::gemm_nn_kernel<T, MW, NT>), grid, block, lds, stream, a);
   }
   template <class T, int NT>
   void launch_mw(bool tn, int mw, dim3 grid, const k::GemmArgs<T>& a) {
@@ -538,6 +602,7 @@ class HipDev {
     a.tiles_total = tiles_total;
     a.tiles_per_split = (tiles_total + nsplit - 1) / nsplit;
     a.nsplit = nsplit;
+    a.debug_flags = gemm_debug_flags_;
     a.slab = nullptr;
     a.slab_stride = (int64_t)out.ld * cb.cols_alloc;
     if (nsplit > 1) a.slab = (T*)alloc_bytes((size_t)nsplit * (size_t)a.slab_stride * sizeof(T));

@@ -74,6 +74,11 @@ struct MT<double> {
 };
 
 constexpr int kRowBytes = 256;  // LDS row of the k-contiguous images
+#ifndef CORRLA_PD
+#define CORRLA_PD 4
+#endif
+constexpr int kPrefetchSteps = CORRLA_PD;  // LDS fragment reads run this many MFMA steps ahead
+constexpr int kLoaders = 4;      // LDS-DMA loader waves per workgroup (besides the 4 MFMA waves); 1 or 2
 // A workgroup owns 64*MW outer indices (4 waves x MW 16-wide MFMA tiles each).  MW = 2 halves the
 // skinny-operand bytes staged per MFMA (the per-CU global->LDS fill rate, ~11 B/clk, is what bounds
 // the MW = 1 shape at 144 columns: 52 KiB per 4608 MFMA cycles); MW = 1 keeps small problems spread
@@ -81,7 +86,16 @@ constexpr int kRowBytes = 256;  // LDS row of the k-contiguous images
 __host__ __device__ constexpr int outer_tile(int mw) { return 64 * mw; }
 __host__ __device__ constexpr int big_tile_bytes(int mw) { return 64 * 256 * mw; }
 __host__ __device__ constexpr int stage_bytes(int mw, int nt) { return big_tile_bytes(mw) + nt * 16 * kRowBytes; }
-__host__ __device__ constexpr int gemm_lds_bytes(int mw, int nt) { return 2 * stage_bytes(mw, nt); }
+// LDS ring depth: 3 stages (the loaders run two tiles ahead, which hides the higher memory latency of the
+// chip's low-clock state between bursts) whenever they fit in 160 KiB, else 2.
+__host__ __device__ constexpr int gemm_stages(int mw, int nt) { return 3 * stage_bytes(mw, nt) <= 160 * 1024 ? 3 : 2; }
+__host__ __device__ constexpr int gemm_lds_bytes(int mw, int nt) { return gemm_stages(mw, nt) * stage_bytes(mw, nt); }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 template <class T>
 struct GemmArgs {
@@ -98,6 +112,7 @@ struct GemmArgs {
   int tiles_total;    // reduction tiles (of KT elements)
   int tiles_per_split;
   int nsplit;
+  int debug_flags;    // timing-only ablation (wrong results): 1 = no DMA after the first tile
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -106,12 +121,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 }
 
 
-// ---- explicit LDS fragment pipeline (cdna_hip_programming.md 5.7) --------------------------------
-// hipcc (ROCm 7.2) brackets every LDS fragment read of this loop with s_waitcnt lgkmcnt(0), which
-// exposes the full LDS latency to the single wave per SIMD.  The fragment reads are therefore
-// issued as inline-asm ds_read_* PD steps ahead of their MFMAs, and retired by hand-counted
-// s_waitcnt lgkmcnt(N) statements that take the fragment as a "+v" operand: the data dependence
-// keeps every consumer below its wait, and volatile asm keeps reads and waits in program order.
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -119,6 +128,36 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<I + 1, N>(f);
   }
 }
+
+// A lean LDS-DMA stream for the loader wave: NVAR per-lane source pointers (one per variant of the
+// repeating swizzle pattern), issued NQ times each with a uniform byte stride between repeats; per DMA
+// the wave spends one 64-bit pointer add.  Chunk i = p + NVAR*q lands at lds + i KiB.
+template <int NVAR, int NQ, int CS>
+struct DmaStream {
+  const char* ptr[NVAR];
+  int64_t step;  // bytes between repeat q and q+1 of a variant
+  int64_t adv;   // bytes per reduction tile
+  // lds = address of this loader's first chunk; its chunks are CS KiB apart (CS = number of loader waves)
+  __device__ __forceinline__ void issue(char* lds) {
+    static_for<0, NQ>([&](auto iq) {
+      static_for<0, NVAR>([&](auto ip) {
+        constexpr int q = decltype(iq)::value, pv = decltype(ip)::value;
+        glds16(ptr[pv], lds + CS * (pv + NVAR * q) * 1024);
+        ptr[pv] += step;
+      });
+    });
+    const int64_t back = adv - (int64_t)NQ * step;
+#pragma unroll
+    for (int pv = 0; pv < NVAR; ++pv) ptr[pv] += back;
+  }
+};
+
+// ---- explicit LDS fragment pipeline (cdna_hip_programming.md 5.7) --------------------------------
+// hipcc (ROCm 7.2) brackets every LDS fragment read of this loop with s_waitcnt lgkmcnt(0), which
+// exposes the full LDS latency to the single wave per SIMD.  The fragment reads are therefore
+// issued as inline-asm ds_read_* PD steps ahead of their MFMAs, and retired by hand-counted
+// s_waitcnt lgkmcnt(N) statements that take the fragment as a "+v" operand: the data dependence
+// keeps every consumer below its wait, and volatile asm keeps reads and waits in program order.
 template <int OFF, class V>
 __device__ __forceinline__ void lds_read_b128(V& d, unsigned addr) {
   static_assert(sizeof(V) == 16 && OFF >= 0 && OFF < 65536, "ds_read_b128 operand");
@@ -174,7 +213,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename 
 // gemm_nn: grid = (ceil(R_rows/64), column blocks, nsplit)
 // ---------------------------------------------------------------------------------------------
 template <class T, int MW, int NT>
-__global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs<T> g) {
+__global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T> g) {
   typedef typename MT<T>::acc_t acc_t;
   typedef typename MT<T>::vec_t vec_t;
   constexpr int VEC = MT<T>::VEC;
@@ -196,43 +235,80 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs<T> g) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[mw][t] = (acc_t){0, 0, 0, 0};
 
-  // Per-lane DMA sources, hoisted out of the k loop.  Chunk c = wave + 4*i covers tile rows 4c..4c+3;
-  // this lane fills physical 16-byte slot (lane & 15) of row 4c + (lane >> 4) with logical slot
-  // ls = slot ^ (row & 15) -- and (row & 15) = (4*wave + (lane >> 4)) & 15 does not depend on i.
-  const int ls = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
-  const int64_t koff = (int64_t)ls * VEC;
-  const T* bigp[4 * MW];
-  bool bigok[4 * MW];
+  // Waves 0..3 are MFMA waves; waves 4.. (kLoaders of them) are LOADER waves that only issue the LDS-DMA of the next tile
+  // (a global_load_lds costs its issuing wave ~100 cycles, which an in-order MFMA wave cannot hide: with
+  // the DMA issued from the MFMA waves this kernel lost 14 %).  Chunk c (1 KiB = 4 tile rows): lane
+  // (r = lane >> 4, s = lane & 15) fills physical 16-byte slot s of row 4c + r with logical slot
+  // s ^ (row & 15).
+  if (wave >= 4) {
+    __builtin_amdgcn_s_setprio(3);  // few instructions, but they gate everyone: win the issue arbitration
+    // generic (bounds-checked) issue of one tile: used for edge tiles only
+    auto stage_checked = [&](int buf, int kt) {
+      char* rt = smem + buf * STAGE;
+      const int64_t k0 = (int64_t)kt * KT;
+      for (int c = wave - 4; c < 16 * MW; c += kLoaders) {
+        const int row = 4 * c + (lane >> 4);
+        const int ls = (lane & 15) ^ (row & 15);
+        const int64_t grow = row0 + row;
+        const int64_t kk = k0 + ls * VEC;
+        const T* src = (grow < g.r_rows && kk < g.r_cols_readable) ? g.r + grow * g.r_ld + kk : g.zero;
+        glds16(src, rt + c * 1024);
+      }
+      for (int c = wave - 4; c < 4 * NT; c += kLoaders) {
+        const int row = 4 * c + (lane >> 4);
+        const int ls = (lane & 15) ^ (row & 15);
+        glds16(g.x + (col0 + row) * g.x_ld + k0 + ls * VEC, rt + BIG + c * 1024);
+      }
+    };
+    // pattern streams: chunk c covers tile rows 4c..4c+3 and (row & 15) repeats every 4 chunks; loader lw
+    // of NL owns chunks c = lw + NL*i, i.e. NV = 4/NL pattern variants, each repeating every 16 rows
+    constexpr int NL = kLoaders, NV = 4 / NL;
+    const int lw = wave - 4;
+    DmaStream<NV, 4 * MW, NL> big;
+    DmaStream<NV, NT, NL> sk;
 #pragma unroll
-  for (int i = 0; i < 4 * MW; ++i) {
-    const int64_t grow = row0 + 4 * (wave + 4 * i) + (lane >> 4);
-    bigok[i] = grow < g.r_rows;
-    bigp[i] = g.r + grow * g.r_ld + koff;
+    for (int pv = 0; pv < NV; ++pv) {
+      const int row = 4 * (lw + NL * pv) + (lane >> 4);
+      const int ls = (lane & 15) ^ (row & 15);
+      big.ptr[pv] = (const char*)(g.r + (row0 + row) * g.r_ld + (int64_t)t_begin * KT + ls * VEC);
+      sk.ptr[pv] = (const char*)(g.x + (col0 + row) * g.x_ld + (int64_t)t_begin * KT + ls * VEC);
+    }
+    big.step = 16 * g.r_ld * (int64_t)sizeof(T);
+    big.adv = KT * (int64_t)sizeof(T);
+    sk.step = 16 * g.x_ld * (int64_t)sizeof(T);
+    sk.adv = KT * (int64_t)sizeof(T);
+    const bool rows_inside = row0 + outer_tile(MW) <= g.r_rows;
+    auto stage_tile = [&](int buf, int kt) {
+      char* rt = smem + buf * STAGE;
+      if (rows_inside && (int64_t)(kt + 1) * KT <= g.r_cols_readable) {
+        big.issue(rt + lw * 1024);
+        sk.issue(rt + BIG + lw * 1024);
+      } else {
+        stage_checked(buf, kt);
+#pragma unroll
+        for (int pv = 0; pv < NV; ++pv) {  // keep the streams in step with the tile counter
+          big.ptr[pv] += big.adv;
+          sk.ptr[pv] += sk.adv;
+        }
+      }
+    };
+    // ring of NSTAGE buffers: tiles i+1 .. i+NSTAGE-1 are in flight while the MFMA waves work on tile i
+    constexpr int NSTAGE = gemm_stages(MW, NT);
+    static_assert((16 * MW) % kLoaders == 0 && (4 * NT) % kLoaders == 0, "chunks must split evenly over the loaders");
+    constexpr int DPL = (16 * MW + 4 * NT) / kLoaders;  // DMA instructions per loader wave per tile
+    for (int t = 0; t < NSTAGE - 1 && t < nk; ++t) stage_tile(t % NSTAGE, t_begin + t);
+    for (int i = 0; i < nk; ++i) {
+      // tile i must have landed; the (NSTAGE-2) younger tiles may stay in flight (vmcnt counts in issue order)
+      if (NSTAGE > 2 && i + NSTAGE - 2 < nk)
+        wait_vmcnt<(NSTAGE - 2) * DPL>();
+      else
+        wait_vmcnt<0>();
+      wg_barrier();  // tile i visible to the MFMA waves; they are done reading buffer (i-1) % NSTAGE
+      if (i + NSTAGE - 1 < nk && !(g.debug_flags & 1)) stage_tile((i + NSTAGE - 1) % NSTAGE, t_begin + i + NSTAGE - 1);
+    }
+    return;
   }
-  const T* skp[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) skp[i] = g.x + (col0 + 4 * (wave + 4 * i) + (lane >> 4)) * g.x_ld + koff;
 
-  // issue slice `part` (0..3) of the DMA for reduction tile kt into buffer `buf`
-  auto stage_part = [&](int buf, int kt, int part) {
-    char* rt = smem + buf * STAGE;
-    const int64_t k0 = (int64_t)kt * KT;
-    const bool kin = k0 + koff < g.r_cols_readable;
-#pragma unroll
-    for (int i = 0; i < 4 * MW; ++i) {
-      if ((i & 3) != part) continue;
-      const T* src = (bigok[i] && kin) ? bigp[i] + k0 : g.zero;
-      glds16(src, rt + (wave + 4 * i) * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      if ((i & 3) != part) continue;
-      glds16(skp[i] + k0, rt + BIG + (wave + 4 * i) * 1024);
-    }
-  };
-
-  // wave w owns tile rows [16*MW*w, 16*MW*(w+1)); the next tile's DMA issue is spread over the four
-  // fragment groups so it runs in the shadow of the MFMAs instead of ahead of them
   // Fragment read addresses (bytes inside a stage), lane-invariant across tiles: for fragment group
   // gq this lane reads 16-byte slot (4*gq + kq) ^ c of its row in both images.
   const int fc = lane & 15, fkq = lane >> 4;
@@ -248,9 +324,9 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs<T> g) {
   // Step st = gq*NT + t consumes one skinny fragment a(st) and the MW big-operand fragments b(gq) in
   // MW*VEC MFMAs.  Reads for step st+PD are issued before the MFMAs of step st; the wait for step
   // st leaves exactly the younger reads (steps st+1..st+PD) in flight.
-  auto compute = [&](int buf, bool prefetch, int nbuf, int nkt) {
+  auto compute = [&](int buf) {
     constexpr int NS = 4 * NT;
-    constexpr int PD = (MW == 1) ? 3 : 2;
+    constexpr int PD = kPrefetchSteps;
     const unsigned sb = (unsigned)(buf * STAGE);
     vec_t afr[NS];
     vec_t bfr[4][MW];
@@ -270,9 +346,6 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs<T> g) {
       constexpr int st = decltype(ic)::value;
       constexpr int gq = st / NT, t = st % NT;
       if constexpr (st + PD < NS) read_step(std::integral_constant<int, st + PD>{});
-      if constexpr (t == 0) {
-        if (prefetch) stage_part(nbuf, nkt, gq);
-      }
       // reads younger than a(st): steps st+1 .. min(st+PD, NS-1), each 1 read (+MW when it opens a group)
       constexpr int last = (st + PD < NS) ? st + PD : NS - 1;
       constexpr int groups = last / NT - gq;  // fragment groups opened by the younger steps
@@ -288,14 +361,9 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs<T> g) {
     });
   };
 
-  if (nk > 0) {
-#pragma unroll
-    for (int part = 0; part < 4; ++part) stage_part(0, t_begin, part);
-  }
   for (int i = 0; i < nk; ++i) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile i has landed for every wave; everyone is done reading buffer (i+1)&1
-    compute(i & 1, i + 1 < nk, (i + 1) & 1, t_begin + i + 1);
+    wg_barrier();  // matches the loaders' barrier: tile i is in LDS (all of this wave's LDS reads are retired)
+    compute(i % gemm_stages(MW, NT));
   }
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw)
@@ -306,7 +374,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs<T> g) {
 // gemm_tn: grid = (ceil(R_cols/64), column blocks, nsplit); reduction over the rows of R
 // ---------------------------------------------------------------------------------------------
 template <class T, int MW, int NT>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
+__global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T> g) {
   typedef typename MT<T>::acc_t acc_t;
   typedef typename MT<T>::vec_t vec_t;
   constexpr int VEC = MT<T>::VEC;
@@ -330,43 +398,83 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[mw][t] = (acc_t){0, 0, 0, 0};
 
-  // Per-lane DMA sources, hoisted out of the reduction loop.  The big tile is a row-linear LDS image
-  // of KT reduction rows x (64*MW outer columns); chunk c = wave + 4*i, 16-byte slot lin = 64c + lane.
-  const T* bigp[4 * MW];
-  int bigrow[4 * MW];
-  bool bigok[4 * MW];
+  // The loader wave (4) issues the LDS-DMA, waves 0..3 run the MFMAs (see gemm_nn).  The big tile is a
+  // row-linear LDS image of KT reduction rows x (64*MW outer columns); 16-byte slot lin = 64c + lane of
+  // chunk c holds logical slot (lin % LPR) ^ tswz(row) of row lin / LPR.
+  if (wave >= 4) {
+    __builtin_amdgcn_s_setprio(3);
+    auto stage_checked = [&](int buf, int mt) {
+      char* rt = smem + buf * STAGE;
+      const int64_t m0 = (int64_t)mt * KT;
+      for (int c = wave - 4; c < 16 * MW; c += kLoaders) {
+        const int lin = c * 64 + lane;
+        const int row = lin / LPR;
+        const int lsb = (lin % LPR) ^ MT<T>::tswz(row);
+        const int64_t grow = m0 + row;
+        const int64_t nn = n0 + (int64_t)lsb * VEC;
+        const T* src = (grow < g.r_rows && nn < g.r_cols_readable) ? g.r + grow * g.r_ld + nn : g.zero;
+        glds16(src, rt + c * 1024);
+      }
+      for (int c = wave - 4; c < 4 * NT; c += kLoaders) {
+        const int row = 4 * c + (lane >> 4);
+        const int ls = (lane & 15) ^ (row & 15);
+        glds16(g.x + (col0 + row) * g.x_ld + m0 + ls * VEC, rt + BIG + c * 1024);
+      }
+    };
+    // big tile: the (row, swizzle) pattern of chunk c repeats every 8 chunks = 8*64/LPR tile rows; loader lw
+    // of NL owns chunks c = lw + NL*i
+    constexpr int NL = kLoaders, NVB = 8 / NL, NV = 4 / NL;
+    const int lw = wave - 4;
+    DmaStream<NVB, 2 * MW, NL> big;
+    DmaStream<NV, NT, NL> sk;
 #pragma unroll
-  for (int i = 0; i < 4 * MW; ++i) {
-    const int lin = (wave + 4 * i) * 64 + lane;
-    const int row = lin / LPR;
-    const int lsb = (lin % LPR) ^ MT<T>::tswz(row);
-    const int64_t nn = n0 + (int64_t)lsb * VEC;
-    bigrow[i] = row;
-    bigok[i] = nn < g.r_cols_readable;
-    bigp[i] = g.r + (int64_t)row * g.r_ld + nn;
+    for (int pv = 0; pv < NVB; ++pv) {
+      const int lin = (lw + NL * pv) * 64 + lane;
+      const int row = lin / LPR;
+      const int lsb = (lin % LPR) ^ MT<T>::tswz(row);
+      big.ptr[pv] = (const char*)(g.r + ((int64_t)t_begin * KT + row) * g.r_ld + n0 + (int64_t)lsb * VEC);
+    }
+#pragma unroll
+    for (int pv = 0; pv < NV; ++pv) {
+      const int row = 4 * (lw + NL * pv) + (lane >> 4);
+      const int ls = (lane & 15) ^ (row & 15);
+      sk.ptr[pv] = (const char*)(g.x + (col0 + row) * g.x_ld + (int64_t)t_begin * KT + ls * VEC);
+    }
+    big.step = (int64_t)(8 * 64 / LPR) * g.r_ld * (int64_t)sizeof(T);
+    big.adv = (int64_t)KT * g.r_ld * (int64_t)sizeof(T);
+    sk.step = 16 * g.x_ld * (int64_t)sizeof(T);
+    sk.adv = KT * (int64_t)sizeof(T);
+    const bool cols_inside = n0 + outer_tile(MW) <= g.r_cols_readable;
+    auto stage_tile = [&](int buf, int mt) {
+      char* rt = smem + buf * STAGE;
+      if (cols_inside && (int64_t)(mt + 1) * KT <= g.r_rows) {
+        big.issue(rt + lw * 1024);
+        sk.issue(rt + BIG + lw * 1024);
+      } else {
+        stage_checked(buf, mt);
+#pragma unroll
+        for (int pv = 0; pv < NVB; ++pv) big.ptr[pv] += big.adv;
+#pragma unroll
+        for (int pv = 0; pv < NV; ++pv) sk.ptr[pv] += sk.adv;
+      }
+    };
+    // ring of NSTAGE buffers: tiles i+1 .. i+NSTAGE-1 are in flight while the MFMA waves work on tile i
+    constexpr int NSTAGE = gemm_stages(MW, NT);
+    static_assert((16 * MW) % kLoaders == 0 && (4 * NT) % kLoaders == 0, "chunks must split evenly over the loaders");
+    constexpr int DPL = (16 * MW + 4 * NT) / kLoaders;  // DMA instructions per loader wave per tile
+    for (int t = 0; t < NSTAGE - 1 && t < nk; ++t) stage_tile(t % NSTAGE, t_begin + t);
+    for (int i = 0; i < nk; ++i) {
+      // tile i must have landed; the (NSTAGE-2) younger tiles may stay in flight (vmcnt counts in issue order)
+      if (NSTAGE > 2 && i + NSTAGE - 2 < nk)
+        wait_vmcnt<(NSTAGE - 2) * DPL>();
+      else
+        wait_vmcnt<0>();
+      wg_barrier();  // tile i visible to the MFMA waves; they are done reading buffer (i-1) % NSTAGE
+      if (i + NSTAGE - 1 < nk && !(g.debug_flags & 1)) stage_tile((i + NSTAGE - 1) % NSTAGE, t_begin + i + NSTAGE - 1);
+    }
+    return;
   }
-  const int ls = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
-  const T* skp[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) skp[i] = g.x + (col0 + 4 * (wave + 4 * i) + (lane >> 4)) * g.x_ld + (int64_t)ls * VEC;
 
-  auto stage_part = [&](int buf, int mt, int part) {
-    char* rt = smem + buf * STAGE;
-    const int64_t m0 = (int64_t)mt * KT;
-#pragma unroll
-    for (int i = 0; i < 4 * MW; ++i) {
-      if ((i & 3) != part) continue;
-      const T* src = (bigok[i] && m0 + bigrow[i] < g.r_rows) ? bigp[i] + m0 * g.r_ld : g.zero;
-      glds16(src, rt + (wave + 4 * i) * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      if ((i & 3) != part) continue;
-      glds16(skp[i] + m0, rt + BIG + (wave + 4 * i) * 1024);
-    }
-  };
-
-  // wave w owns tile columns [16*MW*w, 16*MW*(w+1))
   // Fragment read addresses (bytes inside a stage), lane-invariant across tiles.  Skinny image: as in
   // gemm_nn.  Big image: element (reduction row mloc, outer column ncol) sits at
   // mloc*RBT + ((ncol/VEC) ^ tswz(mloc))*16 + (ncol%VEC)*sizeof(T); for this lane mloc =
@@ -383,9 +491,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
                                   (ncol % VEC) * (int)sizeof(T));
   }
 
-  auto compute = [&](int buf, bool prefetch, int nbuf, int nmt) {
+  auto compute = [&](int buf) {
     constexpr int NS = 4 * NT;
-    constexpr int PD = (MW == 1) ? 3 : 2;
+    constexpr int PD = kPrefetchSteps;
     const unsigned sb = (unsigned)(buf * STAGE);
     vec_t afr[NS];
     T bfr[4][MW][VEC];
@@ -405,9 +513,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
       constexpr int st = decltype(ic)::value;
       constexpr int gq = st / NT, t = st % NT;
       if constexpr (st + PD < NS) read_step(std::integral_constant<int, st + PD>{});
-      if constexpr (t == 0) {
-        if (prefetch) stage_part(nbuf, nmt, gq);
-      }
       constexpr int last = (st + PD < NS) ? st + PD : NS - 1;
       constexpr int groups = last / NT - gq;
       constexpr int younger = (last - st) + groups * MW * VEC;
@@ -422,14 +527,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs<T> g) {
     });
   };
 
-  if (nk > 0) {
-#pragma unroll
-    for (int part = 0; part < 4; ++part) stage_part(0, t_begin, part);
-  }
   for (int i = 0; i < nk; ++i) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    compute(i & 1, i + 1 < nk, (i + 1) & 1, t_begin + i + 1);
+    wg_barrier();
+    compute(i % gemm_stages(MW, NT));
   }
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw)
@@ -948,6 +1048,22 @@ __global__ __launch_bounds__(1024) void jacobi_finish_kernel(const T* w, int64_t
     }
     if (gl == 0) s_out[r] = sj;
   }
+}
+
+// ---- (I + E)^(-1/2) by its Taylor series, for the polishing pass of the Cholesky-QR ---------------
+// g (r x r, column-major, ld) holds G = I + E on entry, E on exit
+template <class T>
+__global__ void series_prep_kernel(T* g, int64_t ld, int r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i < r && j < r && i == j) g[(int64_t)j * ld + i] -= (T)1;
+}
+// m = I - E/2 + 3 E^2 / 8 - 5 E^3 / 16
+template <class T>
+__global__ void series_combine_kernel(const T* e1, const T* e2, const T* e3, int64_t ld, int r, T* m, int64_t ldm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= r || j >= r) return;
+  const int64_t o = (int64_t)j * ld + i;
+  m[(int64_t)j * ldm + i] = (i == j ? (T)1 : (T)0) - (T)0.5 * e1[o] + (T)0.375 * e2[o] - (T)0.3125 * e3[o];
 }
 
 // ---- layout helpers --------------------------------------------------------------------------

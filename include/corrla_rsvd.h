@@ -83,6 +83,8 @@ typedef struct corrla_timings {
   double finalize_ms;   /* U = Q*Ut, output copies           random_svd.rs:92-109  */
   int32_t qr_passes;    /* Gram/whitening passes used by all orthonormalisations */
   int32_t reserved;
+  double sketch_kernel_ms; /* device time of the sketch GEMM launch(es) of this call: hipEvents recorded on the
+                              context's stream around Y = A*Omega (no extra synchronisation) */
 } corrla_timings;
 
 /* ---- library / context ------------------------------------------------------------- */

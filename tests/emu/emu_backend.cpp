@@ -64,6 +64,8 @@ class EmuDev {
   void begin_call() { blocks.clear(); }
   void end_call() {}
   void sync() {}
+  void event_mark(int) {}
+  double event_elapsed_ms(int, int) { return 0.0; }
   void* alloc_bytes(size_t bytes) {
     blocks.emplace_back(new char[bytes + 64]);
     char* p = blocks.back().get();
@@ -161,6 +163,22 @@ class EmuDev {
   }
   template <class T>
   void store_values(const T* src, int64_t n, T* dst, bool) { std::memcpy(dst, src, sizeof(T) * n); }
+  template <class T>
+  void inv_sqrt_series(Skinny<T>& g, int64_t r, Skinny<T>& m_out) {
+    std::vector<double> e((size_t)r * r), e2((size_t)r * r, 0.0), e3((size_t)r * r, 0.0);
+    for (int64_t j = 0; j < r; ++j)
+      for (int64_t i = 0; i < r; ++i) e[j * r + i] = (double)g.p[j * g.ld + i] - (i == j ? 1.0 : 0.0);
+    for (int64_t j = 0; j < r; ++j)
+      for (int64_t i = 0; i < r; ++i)
+        for (int64_t kk = 0; kk < r; ++kk) e2[j * r + i] += e[kk * r + i] * e[j * r + kk];
+    for (int64_t j = 0; j < r; ++j)
+      for (int64_t i = 0; i < r; ++i)
+        for (int64_t kk = 0; kk < r; ++kk) e3[j * r + i] += e[kk * r + i] * e2[j * r + kk];
+    std::memset(m_out.p, 0, (size_t)m_out.ld * m_out.cols_alloc * sizeof(T));
+    for (int64_t j = 0; j < r; ++j)
+      for (int64_t i = 0; i < r; ++i)
+        m_out.p[j * m_out.ld + i] = (T)((i == j ? 1.0 : 0.0) - 0.5 * e[j * r + i] + 0.375 * e2[j * r + i] - 0.3125 * e3[j * r + i]);
+  }
   template <class T>
   void copy_values_out(const T* src, int64_t n, T* dst, bool) { std::memcpy(dst, src, sizeof(T) * n); }
   template <class T>

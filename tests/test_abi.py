@@ -37,7 +37,7 @@ def test_header_symbols_all_exported_and_bound(lib):
 
 def test_struct_layouts_match_header(lib):
     assert C.sizeof(L.Opts) == 32          # u32 u32 u64 ptr i64
-    assert C.sizeof(L.Timings) == 7 * 8 + 8
+    assert C.sizeof(L.Timings) == 7 * 8 + 8 + 8
 
 
 def test_version_and_error_strings(lib):
