@@ -76,6 +76,10 @@ class HipDev {
     set_lds_attrs<double>();
     set_jacobi_attrs<float>();
     set_jacobi_attrs<double>();
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<float>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<double>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_block_round_kernel<float>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_block_round_kernel<double>,
@@ -360,6 +364,22 @@ class HipDev {
     const T tol_early = (T)std::sqrt(eps);  // quadratic convergence: a sweep that starts below this ends below tol
     const bool v_lds = lds2 <= kLdsMax;
     const size_t lds = v_lds ? lds2 : lds1;
+    // role-split kernel: W updates and V updates on different waves (needs both images in LDS, <= 72 pairs,
+    // <= 36 sixteen-byte chunks per column)
+    const size_t lds_split = k::jacobi_split_lds_bytes((int)l, sizeof(T));
+    const int nchunk_s = k::jacobi_pitch((int)l, (int)(16 / sizeof(T))) / (int)(16 / sizeof(T));
+    if (lds_split <= kLdsMax && (l + 1) / 2 <= 72 && nchunk_s <= 36 && !env_int("CORRLA_JACOBI_NOSPLIT", 0)) {
+      hipLaunchKernelGGL((k::jacobi_svd_split_kernel<T>), dim3(1), dim3(1024), lds_split, stream, (const T*)c.p, c.ld,
+                         (int)l, m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, tol_early, 40, info);
+      CORRLA_HIP(hipGetLastError());
+      if (env_int("CORRLA_DEBUG", 0)) {
+        int h[4] = {0, 0, 0, 0};
+        CORRLA_HIP(hipMemcpyAsync(h, info, sizeof(int), hipMemcpyDeviceToHost, stream));
+        sync();
+        std::fprintf(stderr, "[corrla] jacobi_svd (split) l=%d sweeps=%d\n", (int)l, h[0]);
+      }
+      return;
+    }
 #define CORRLA_JACOBI(VL, G, E)                                                                                      \
   hipLaunchKernelGGL((k::jacobi_svd_kernel<T, VL, G, E>), dim3(1), dim3(1024), lds, stream, (const T*)c.p, c.ld, (int)l, \
                      vg, ldv, m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, tol_early, 40, info)

@@ -653,12 +653,60 @@ __global__ void fill_normal_kernel(T* p, int64_t rows, int64_t cols, int64_t rs,
 // C = U_c diag(sigma) V_c^T.  The kernel sorts sigma descending and writes sigma[:k], V_c[:, :k]
 // (-> m1) and U_c[:, :k] (-> m2) directly into the zero-padded skinny operands of the GEMMs that
 // follow (U = Q * m1, V = Qb * m2), so the final stage needs no host round trip.
+// Jacobi rotation (cos, sin) that annihilates the off-diagonal g of [[a, g], [g, b]]; `rel` receives
+// |g| / sqrt(a b).  f32 uses the single-instruction reciprocal / rsqrt (~1 ulp; the Jacobi kernels are
+// VALU-issue bound and the IEEE sqrt/div sequences were ~1/4 of their instruction stream); f64 stays IEEE.
+__device__ __forceinline__ bool jacobi_rotation(float a, float b, float g, float tol, float& cs, float& sn, float& rel) {
+  const float ab2 = a * b;
+  const float rs = ab2 > 0.f ? __builtin_amdgcn_rsqf(ab2) : 0.f;
+  rel = fabsf(g) * rs;
+  if (!(rel > tol)) return false;
+  const float zeta = (b - a) * 0.5f * __builtin_amdgcn_rcpf(g);
+  const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta);
+  const float t = copysignf(__builtin_amdgcn_rcpf(den), zeta);
+  cs = __builtin_amdgcn_rsqf(1.f + t * t);
+  sn = cs * t;
+  return true;
+}
+__device__ __forceinline__ bool jacobi_rotation(double a, double b, double g, double tol, double& cs, double& sn,
+                                                double& rel) {
+  const double ab = sqrt(a * b);
+  rel = ab > 0.0 ? fabs(g) / ab : 0.0;
+  if (!(rel > tol)) return false;
+  const double zeta = (b - a) / (2.0 * g);
+  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  cs = 1.0 / sqrt(1.0 + t * t);
+  sn = cs * t;
+  return true;
+}
+// pair (p < q) of slot `pr` in round `step` of the round-robin tournament on n players (no integer division)
+__device__ __forceinline__ void tournament_pair(int n, int step, int pr, int& p, int& q) {
+  if (pr == 0) {
+    p = n - 1;
+    q = step;
+  } else {
+    p = step + pr;
+    if (p >= n - 1) p -= n - 1;
+    q = step - pr;
+    if (q < 0) q += n - 1;
+  }
+  if (p > q) {
+    const int t_ = p;
+    p = q;
+    q = t_;
+  }
+}
 // column pitch of the LDS-resident Jacobi images: multiple of the 16-byte vector width, and an odd number
 // of 16-byte slots so consecutive columns start on different bank groups
 __host__ __device__ inline int jacobi_pitch(int l, int vw) {
   int slots = (l + vw - 1) / vw;
   slots |= 1;
   return slots * vw;
+}
+// W + V images, sigma, order, flags
+__host__ __device__ inline size_t jacobi_lds_bytes_fwd(int l, size_t esz) {
+  const int vw = (int)(16 / esz);
+  return (size_t)l * jacobi_pitch(l, vw) * esz * 2 + (size_t)(l + 2) * esz + (size_t)(l + 2) * sizeof(int) + 64;
 }
 template <class T, bool V_IN_LDS, int G, int E>
 __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ c, int64_t ldc, int l, T* vg, int64_t ldv,
@@ -697,18 +745,7 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
     for (int step = 0; step < n - 1; ++step) {
       for (int pr = group; pr < npairs; pr += NG) {
         int p, q;
-        if (pr == 0) {
-          p = n - 1;
-          q = step;
-        } else {
-          p = (step + pr) % (n - 1);
-          q = (step - pr + (n - 1)) % (n - 1);
-        }
-        if (p > q) {
-          const int t_ = p;
-          p = q;
-          q = t_;
-        }
+        tournament_pair(n, step, pr, p, q);
         if (q >= l) continue;  // the dummy player (uniform within the group)
         vec_t* wp = (vec_t*)(w + p * LP);
         vec_t* wq = (vec_t*)(w + q * LP);
@@ -742,13 +779,8 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
           b += __shfl_xor(b, msk, G);
           g += __shfl_xor(g, msk, G);
         }
-        const T ab = sqrt(a * b);
-        const T ag = fabs(g);
-        if (ag > tol * ab && ab > (T)0) {
-          const T zeta = (b - a) / ((T)2 * g);
-          const T t = (zeta >= (T)0 ? (T)1 : (T)-1) / (fabs(zeta) + sqrt((T)1 + zeta * zeta));
-          const T cs = (T)1 / sqrt((T)1 + t * t);
-          const T sn = cs * t;
+        T cs, sn, rel;
+        if (jacobi_rotation(a, b, g, tol, cs, sn, rel)) {
 #pragma unroll
           for (int e = 0; e < E; ++e) {
             const int ch = gl + G * e;
@@ -761,7 +793,7 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
           }
           if (gl == 0) {
             flag[0] = 1;
-            if (ag > tol_early * ab) flag[1] = 1;
+            if (rel > tol_early) flag[1] = 1;
           }
         }
       }
@@ -808,6 +840,188 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
   }
   if (tid == 0) info[0] = sweep;
 }
+// Role-split variant of jacobi_svd_kernel for l <= 144 with W and V both in LDS: V never feeds back into
+// the iteration, so waves 0..8 (72 eight-lane groups) compute the rotations and update W only, publishing
+// (cos, sin) per pair in a double-buffered LDS table, while waves 9..15 (112 four-lane groups) apply the
+// PREVIOUS step's rotations to V.  The per-step critical path is the W half; the V half runs beside it.
+template <class T>
+__global__ __launch_bounds__(1024) void jacobi_svd_split_kernel(const T* __restrict__ c, int64_t ldc, int l, T* m1,
+                                                                int64_t ld1, T* m2, int64_t ld2, T* s_out, int k, T tol,
+                                                                T tol_early, int max_sweeps, int* info) {
+  typedef typename MT<T>::vec_t vec_t;
+  constexpr int VW = MT<T>::VEC;
+  constexpr int GW = 8, EW = 5;   // W groups: 8 lanes x 5 chunks  (>= 36 chunks of 16 bytes)
+  constexpr int GV = 4, EV = 9;   // V groups: 4 lanes x 9 chunks
+  constexpr int NWG = 72;         // W groups (waves 0..8)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int LP = jacobi_pitch(l, VW);
+  const int nchunk = LP / VW;
+  T* w = (T*)smem;
+  T* v = w + (size_t)l * LP;
+  T* sigma = v + (size_t)l * LP;
+  int* order = (int*)(sigma + l + 2);
+  int* flag = order + l + 2;
+  T* rot = (T*)(((uintptr_t)(flag + 4) + 15) & ~(uintptr_t)15);  // [2][NWG][2]
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < l * LP; idx += 1024) {
+    const int j = idx / LP, i = idx - j * LP;
+    w[idx] = (i < l) ? c[(int64_t)j * ldc + i] : (T)0;
+    v[idx] = (i == j) ? (T)1 : (T)0;
+  }
+  __syncthreads();
+  const int n = (l + 1) & ~1;
+  const int npairs = n / 2;  // <= NWG
+  const bool is_w = tid < NWG * GW;
+  const int wgroup = tid / GW, wl = tid % GW;
+  const int vgroup = (tid - NWG * GW) / GV, vl = (tid - NWG * GW) % GV;
+  auto pair_of = [&](int step, int pr, int& p, int& q) { tournament_pair(n, step, pr, p, q); };
+  vec_t zero;
+#pragma unroll
+  for (int z = 0; z < VW; ++z) zero[z] = (T)0;
+  // V worker: apply the rotations published for (pstep) from table buffer tb
+  auto v_pass = [&](int pstep, int tb) {
+    if (is_w || vgroup >= npairs) return;
+    int p, q;
+    pair_of(pstep, vgroup, p, q);
+    if (q >= l) return;
+    const T cs = rot[(tb * NWG + vgroup) * 2], sn = rot[(tb * NWG + vgroup) * 2 + 1];
+    if (sn == (T)0) return;
+    vec_t* vp = (vec_t*)(v + p * LP);
+    vec_t* vq = (vec_t*)(v + q * LP);
+    vec_t vx[EV], vy[EV];
+#pragma unroll
+    for (int e = 0; e < EV; ++e) {
+      const int ch = vl + GV * e;
+      const bool in = ch < nchunk;
+      vx[e] = in ? vp[ch] : zero;
+      vy[e] = in ? vq[ch] : zero;
+    }
+#pragma unroll
+    for (int e = 0; e < EV; ++e) {
+      const int ch = vl + GV * e;
+      if (ch < nchunk) {
+        vp[ch] = cs * vx[e] - sn * vy[e];
+        vq[ch] = sn * vx[e] + cs * vy[e];
+      }
+    }
+  };
+  int sweep = 0;
+  int gs = 0;  // global step counter (table parity)
+  int last_step = -1;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid < 2) flag[tid] = 0;
+    __syncthreads();
+    for (int step = 0; step < n - 1; ++step, ++gs) {
+      if (is_w) {
+        if (wgroup < npairs) {
+          int p, q;
+          pair_of(step, wgroup, p, q);
+          T cs = (T)1, sn = (T)0;
+          if (q < l) {
+            vec_t* wp = (vec_t*)(w + p * LP);
+            vec_t* wq = (vec_t*)(w + q * LP);
+            vec_t x[EW], y[EW];
+#pragma unroll
+            for (int e = 0; e < EW; ++e) {
+              const int ch = wl + GW * e;
+              const bool in = ch < nchunk;
+              x[e] = in ? wp[ch] : zero;
+              y[e] = in ? wq[ch] : zero;
+            }
+            T a = 0, b = 0, g = 0;
+#pragma unroll
+            for (int e = 0; e < EW; ++e)
+#pragma unroll
+              for (int z = 0; z < VW; ++z) {
+                a += x[e][z] * x[e][z];
+                b += y[e][z] * y[e][z];
+                g += x[e][z] * y[e][z];
+              }
+#pragma unroll
+            for (int msk = 1; msk < GW; msk <<= 1) {
+              a += __shfl_xor(a, msk, GW);
+              b += __shfl_xor(b, msk, GW);
+              g += __shfl_xor(g, msk, GW);
+            }
+            T rel;
+            if (jacobi_rotation(a, b, g, tol, cs, sn, rel)) {
+#pragma unroll
+              for (int e = 0; e < EW; ++e) {
+                const int ch = wl + GW * e;
+                if (ch < nchunk) {
+                  wp[ch] = cs * x[e] - sn * y[e];
+                  wq[ch] = sn * x[e] + cs * y[e];
+                }
+              }
+              if (wl == 0) {
+                flag[0] = 1;
+                if (rel > tol_early) flag[1] = 1;
+              }
+            } else {
+              cs = (T)1;
+              sn = (T)0;
+            }
+          }
+          if (wl == 0) {
+            rot[((gs & 1) * NWG + wgroup) * 2] = cs;
+            rot[((gs & 1) * NWG + wgroup) * 2 + 1] = sn;
+          }
+        }
+      } else if (last_step >= 0) {
+        v_pass(last_step, (gs - 1) & 1);
+      }
+      last_step = step;
+      __syncthreads();
+    }
+    const int rotated = flag[0], big = flag[1];
+    __syncthreads();
+    if (!rotated || !big) {
+      if (rotated) ++sweep;
+      break;
+    }
+  }
+  // drain: the rotations of the last step have not reached V yet
+  if (last_step >= 0) v_pass(last_step, (gs - 1) & 1);
+  __syncthreads();
+  // singular values, order, outputs
+  const int group = tid >> 4, gl = tid & 15;
+  for (int j = group; j < l; j += 64) {
+    T a = 0;
+    for (int i = gl; i < l; i += 16) {
+      const T xx = w[j * LP + i];
+      a += xx * xx;
+    }
+#pragma unroll
+    for (int msk = 1; msk < 16; msk <<= 1) a += __shfl_xor(a, msk, 16);
+    if (gl == 0) sigma[j] = sqrt(a);
+  }
+  __syncthreads();
+  for (int j = tid; j < l; j += 1024) {
+    const T sj = sigma[j];
+    int r = 0;
+    for (int i = 0; i < l; ++i) {
+      const T si = sigma[i];
+      r += (si > sj || (si == sj && i < j)) ? 1 : 0;
+    }
+    order[r] = j;
+  }
+  __syncthreads();
+  for (int r = group; r < k; r += 64) {
+    const int j = order[r];
+    const T sj = sigma[j];
+    const T inv = sj > (T)0 ? (T)1 / sj : (T)0;
+    for (int i = gl; i < l; i += 16) {
+      m2[(int64_t)r * ld2 + i] = w[j * LP + i] * inv;
+      m1[(int64_t)r * ld1 + i] = v[j * LP + i];
+    }
+    if (gl == 0) s_out[r] = sj;
+  }
+  if (tid == 0) info[0] = sweep;
+}
+__host__ __device__ inline size_t jacobi_split_lds_bytes(int l, size_t esz) {
+  return jacobi_lds_bytes_fwd(l, esz) + 16 + 2 * 72 * 2 * esz;
+}
+
 __host__ __device__ inline size_t jacobi_lds_bytes(int l, size_t esz, bool v_in_lds) {
   const int vw = (int)(16 / esz);
   return (size_t)l * jacobi_pitch(l, vw) * esz * (v_in_lds ? 2 : 1) + (size_t)(l + 2) * esz +
