@@ -288,3 +288,75 @@ def test_c4_like_tall_f32(ctx, torch):
     u, s, vt = ctx.rsvd(a, k, q, p, seed=3)
     re = _device_checks(torch, a, u, s, vt, k, 1.2e-7)
     assert 0.8 < re < 0.999
+
+
+# ---- alternate SVD-of-the-core paths and error handling ------------------------------------------
+@pytest.mark.parametrize("mode", ["block", "host", "nosplit"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_small_svd_paths_agree(ctx, mode, dtype, monkeypatch):
+    """The l x l SVD (random_svd.rs:89) has three device kernels and a host routine; all must give the same
+    factorization as the default path (up to rounding) on a well-separated and on a rank-deficient case."""
+    for name in ("gauss512x256", "rankdef96x40", "lowrank256x96"):
+        g = load_golden(name)
+        a = g["A"].astype(dtype)
+        om = g["omega"].astype(dtype)
+        u0, s0, vt0 = ctx.rsvd(a, g["k"], g["q"], g["p"], omega=om)
+        if mode == "nosplit":
+            monkeypatch.setenv("CORRLA_JACOBI_NOSPLIT", "1")
+        else:
+            monkeypatch.setenv("CORRLA_SVD", mode)
+        u1, s1, vt1 = ctx.rsvd(a, g["k"], g["q"], g["p"], omega=om)
+        monkeypatch.delenv("CORRLA_SVD", raising=False)
+        monkeypatch.delenv("CORRLA_JACOBI_NOSPLIT", raising=False)
+        tol = 1e-10 if dtype == np.float64 else 5e-5
+        assert np.max(np.abs(s1 - s0)) <= tol * s0[0, 0]
+        rec0 = (u0.astype(np.float64) * s0.ravel()) @ vt0.astype(np.float64)
+        rec1 = (u1.astype(np.float64) * s1.ravel()) @ vt1.astype(np.float64)
+        assert np.linalg.norm(rec1 - rec0) <= 50 * tol * np.linalg.norm(rec0)
+
+
+@pytest.mark.parametrize("l_total", [129, 138, 150, 200])
+def test_f64_core_sizes_cross_kernel_boundaries(ctx, l_total):
+    """f64 sketches around the LDS-capacity boundaries of the Jacobi kernels (128 / 138 / block fallback)."""
+    rng = np.random.default_rng(l_total)
+    m, n = 700, 260
+    a = rng.standard_normal((m, n)) * (0.99 ** np.arange(n))  # kappa(sketch) ~ 1e4: tests the kernels, not the conditioning
+    k, p, q = l_total - 10, 10, 2
+    om = rng.standard_normal((n, l_total))
+    u, s, vt = ctx.rsvd(a, k, q, p, omega=om)
+    uo, so, vto = orc.random_svd(a, k, q, p, omega=om)
+    assert np.max(np.abs(s - so)) <= 1e-9 * so[0, 0]
+    assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-9
+    assert orth_err(u) < 1e-11 and orth_err(vt.T) < 1e-11
+
+
+def test_non_finite_input_is_an_error_not_garbage(ctx):
+    from corrla_rs_amd._lib import CorrlaError
+    a = np.ones((64, 32))
+    a[3, 5] = np.nan
+    with pytest.raises(CorrlaError) as e:
+        ctx.rsvd(a, 4, 2, 4)
+    assert e.value.code == 5  # CORRLA_ENUMERIC
+
+
+def test_seed_changes_sketch_not_quality(ctx):
+    rng = np.random.default_rng(9)
+    a = (rng.standard_normal((400, 30)) * (0.5 ** np.arange(30))) @ rng.standard_normal((30, 120))
+    ex = np.linalg.svd(a, compute_uv=False)[:8]
+    u1, s1, vt1 = ctx.rsvd(a, 8, 3, 8, seed=1)
+    u2, s2, vt2 = ctx.rsvd(a, 8, 3, 8, seed=2)
+    assert not np.array_equal(u1, u2)
+    for s_ in (s1, s2):  # leading values converge fast; the trailing ones carry RSVD's own approximation error
+        assert np.allclose(s_.ravel()[:5], ex[:5], rtol=1e-6) and np.allclose(s_.ravel(), ex, rtol=1e-2)
+        assert np.all(s_.ravel() <= ex * (1 + 1e-12))  # Rayleigh-Ritz values never exceed the true ones
+
+
+def test_large_norm_does_not_overflow_f32(ctx):
+    """random_svd.rs:53-55 rescales Y every iteration; sigma_1 ~ 1e9 would overflow f32 after two unscaled
+    power iterations (sigma^5 ~ 1e45)."""
+    rng = np.random.default_rng(4)
+    a = (rng.standard_normal((256, 64)) * 1e9 / 24).astype(np.float32)
+    u, s, vt = ctx.rsvd(a, 6, 4, 6, seed=5)
+    assert np.all(np.isfinite(s)) and np.all(np.isfinite(u)) and np.all(np.isfinite(vt))
+    ex = np.linalg.svd(a.astype(np.float64), compute_uv=False)[:6]
+    assert np.allclose(s.ravel(), ex, rtol=0.15)
