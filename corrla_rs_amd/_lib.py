@@ -42,6 +42,9 @@ def _sigs():
         s["corrla_rsvd_" + suf] = (C.c_int, rsvd)
         s["corrla_rsvd_dev_" + suf] = (C.c_int, rsvd)
         s["corrla_rsvd_sharded_dev_" + suf] = (C.c_int, rsvd)
+        pca = [vp, vp, i64, i64, i64, i64, i64, i64, i64, C.POINTER(Opts), vp, vp, vp, i64]
+        s["corrla_pca_" + suf] = (C.c_int, pca)
+        s["corrla_pca_dev_" + suf] = (C.c_int, pca)
         pw = [vp, vp, i64, i64, i64, i64, i64, i64, C.POINTER(Opts), vp, i64]
         s["corrla_power_iter_" + suf] = (C.c_int, pw)
         s["corrla_power_iter_dev_" + suf] = (C.c_int, pw)

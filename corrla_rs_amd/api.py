@@ -22,7 +22,7 @@ import numpy as np
 
 from . import _lib as L
 
-__all__ = ["Context", "default_context", "rsvd", "random_svd", "power_iter", "algorithmic_flops"]
+__all__ = ["Context", "default_context", "rsvd", "random_svd", "power_iter", "rpca", "PcaRsvd", "algorithmic_flops"]
 
 
 def _is_torch(x):
@@ -180,6 +180,56 @@ class Context:
         matrix as a torch CUDA tensor; returns (U_local, S, Vt) with S, Vt replicated."""
         return self._rsvd_torch(a_local, int(n_rank), int(n_iters), int(n_oversamples), seed, omega, sharded=True)
 
+    # ---- PCA caller (pca_rsvd.rs:56-82) ---------------------------------------------------
+    def pca(self, x_mat, rank, n_iter=None, n_oversamples=None, *, seed=None, omega=None):
+        """PcaRsvd::new(x, rank): returns (means (1, n), singular values (k, 1), components (k, n)).
+        n_iter / n_oversamples default to the reference's hard-coded 20 / min(n_dim, 10) (pca_rsvd.rs:65-66)."""
+        rank = int(rank)
+        if _is_torch(x_mat) and x_mat.is_cuda:
+            import torch
+            x = x_mat if x_mat.dtype in (torch.float32, torch.float64) else x_mat.to(torch.float64)
+            if x.dim() != 2:
+                raise ValueError("x_mat must be 2-D")
+            m, n = x.shape
+            q = 20 if n_iter is None else int(n_iter)
+            p = min(n, 10) if n_oversamples is None else int(n_oversamples)
+            rs, cs = x.stride()
+            nt = min(m, n)
+            l = min(rank + max(p, 0), nt)
+            o, keep = self._opts(seed, omega, nt, l, x.dtype, True)
+            kk = max(rank, 1)
+            means = torch.empty((1, n), dtype=x.dtype, device=x.device)
+            s = torch.empty((kk, 1), dtype=x.dtype, device=x.device)
+            comps = torch.empty((n, kk), dtype=x.dtype, device=x.device).t()
+            torch.cuda.current_stream(x.device).synchronize()
+            fn = getattr(self._lib, "corrla_pca_dev_" + ("f32" if x.dtype == torch.float32 else "f64"))
+            L.check(fn(self._h, x.data_ptr(), m, n, rs, cs, rank, q, p, C.byref(o) if o is not None else None,
+                       means.data_ptr(), s.data_ptr(), comps.data_ptr(), kk))
+            del keep
+            return means, s, comps
+        x = np.asarray(x_mat.detach().cpu().numpy() if _is_torch(x_mat) else x_mat)
+        if x.ndim != 2:
+            raise ValueError("x_mat must be 2-D")
+        if x.dtype != np.float32:
+            x = x.astype(np.float64, copy=False)
+        if any(st < 0 for st in x.strides):
+            x = np.ascontiguousarray(x)
+        m, n = x.shape
+        q = 20 if n_iter is None else int(n_iter)
+        p = min(n, 10) if n_oversamples is None else int(n_oversamples)
+        nt = min(m, n)
+        l = min(rank + max(p, 0), nt)
+        o, keep = self._opts(seed, omega, nt, l, x.dtype, False)
+        kk = max(rank, 1)
+        means = np.empty((1, n), dtype=x.dtype)
+        s = np.empty((kk, 1), dtype=x.dtype)
+        comps = np.empty((kk, n), dtype=x.dtype, order="F")
+        fn = getattr(self._lib, "corrla_pca_" + ("f32" if x.dtype == np.float32 else "f64"))
+        L.check(fn(self._h, x.ctypes.data, m, n, x.strides[0] // x.itemsize, x.strides[1] // x.itemsize, rank, q, p,
+                   C.byref(o) if o is not None else None, means.ctypes.data, s.ctypes.data, comps.ctypes.data, kk))
+        del keep
+        return means, s, comps
+
     # ---- power_iter ----------------------------------------------------------------------
     def power_iter(self, a_mat, omega_rank, n_iter, *, seed=None, omega=None):
         a = np.asarray(a_mat)
@@ -273,6 +323,46 @@ def power_iter(a_mat, omega_rank, n_iter, *, seed=None, omega=None, ctx=None):
     """power_iter(a_mat, omega_rank, n_iter) -> Q (m, omega_rank), random_svd.rs:15-18.  `omega_rank` is
     the already-oversampled sketch width."""
     return (ctx or default_context()).power_iter(a_mat, omega_rank, n_iter, seed=seed, omega=omega)
+
+
+def rpca(a_mat, n_rank, n_iters=None, n_oversamples=None, *, seed=None, omega=None, ctx=None):
+    """pyo3 ``rpca(a_mat, n_rank, n_iters, n_oversamples) -> (singular_values (k, 1), components (k, n))``,
+    src/lib_math_utils_py.rs:38-55.  Like the reference, the last two positional arguments are accepted and
+    IGNORED: PcaRsvd::new hard-codes n_iter = 20 and n_oversamples = min(n_dim, 10) (pca_rsvd.rs:65-66)."""
+    del n_iters, n_oversamples
+    _means, s, comps = (ctx or default_context()).pca(a_mat, n_rank, seed=seed, omega=omega)
+    return s, comps
+
+
+class PcaRsvd:
+    """Mirror of ``PcaRsvd`` (src/lib_math_utils/pca_rsvd.rs:13-112): fit on construction, keeps the means, the
+    singular values (k, 1) and ``components_`` (k, n_dim).  The fit (means, centring, RSVD) runs on the GPU; the
+    two k-wide projections below are plain numpy on the stored k x n_dim factors."""
+
+    def __init__(self, x_mat, rank, *, seed=None, omega=None, ctx=None):
+        self.pca_rank = int(rank)
+        x = np.asarray(x_mat)
+        self.n_samples = x.shape[0]
+        self.means, self.pca_s, self.components_ = (ctx or default_context()).pca(x, rank, seed=seed, omega=omega)
+
+    def fit(self, x_mat, rank, **kw):  # pca_rsvd.rs:85-88
+        self.__init__(x_mat, rank, **kw)
+
+    def explained_var(self):  # pca_rsvd.rs:91-99: s^2 / (n_samples - 1)
+        return self.pca_s * self.pca_s / (self.n_samples - 1.0)
+
+    def components(self):
+        return self.components_
+
+    def singular_values(self):
+        return self.pca_s
+
+    def apply_tr(self, targ_mat):  # pca_rsvd.rs:43-46: centres the TARGET by its own column means
+        t = np.asarray(targ_mat, dtype=self.components_.dtype)
+        return (t - t.mean(axis=0, keepdims=True)) @ self.components_.T
+
+    def apply_inv_tr(self, red_mat):  # pca_rsvd.rs:49-52
+        return np.asarray(red_mat, dtype=self.components_.dtype) @ self.components_ + self.means
 
 
 def algorithmic_flops(m, n, k, q, p):

@@ -162,6 +162,64 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
   if (tm_out) *tm_out = drv.tm;
 }
 
+// PcaRsvd::new (pca_rsvd.rs:56-82): means, centred copy, random_svd of the centred matrix; keeps S and V^T.
+template <class Dev, class T>
+inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank,
+                      int64_t n_iter, int64_t n_oversamples, const corrla_opts* opts, T* means, T* s, T* comps,
+                      int64_t ldc, Timings* tm_out, bool profile) {
+  if (!means || !s || !comps) throw Error(ST_EINVAL, "output pointer is NULL");
+  validate_matrix(x, m, n, rs, cs);
+  validate_rank(m, n, rank, n_iter, n_oversamples);
+  if (m < 2) throw Error(ST_EINVAL, "PCA needs at least two samples");
+  if (ldc < rank) throw Error(ST_EINVAL, "ldc < rank");
+  RunOpts ro = parse_opts(opts, !host_ptrs);
+  dev.begin_call();
+  TallA<T> ta = stage_input<Dev, T>(dev, host_ptrs, x, m, n, rs, cs, false);
+  const bool fat = m < n;  // the tall view is x^T: its ROWS are the data columns
+  // column means of x = (1/m) x^T 1: one pass of the transposed-GEMM kernel against a ones vector
+  RsvdDriver<Dev, T> drv(dev, profile);
+  const int64_t samples_dim_tall = fat ? ta.nt : ta.mt;  // n_samples as a dimension of the tall view
+  Skinny<T> ones = dev.template alloc_skinny<T>(samples_dim_tall, 1);
+  dev.fill_const(ones.p, samples_dim_tall, (T)1);
+  Skinny<T> mu = dev.template alloc_skinny<T>(fat ? ta.mt : ta.nt, 1);
+  T* inv_m = dev.template alloc_scalar<T>(1);
+  const T inv_m_host = (T)(1.0 / (double)m);
+  dev.store_values(&inv_m_host, (int64_t)1, inv_m, /*dst_is_host=*/false);
+  if (!fat)
+    drv.at_times(ta, ones, mu, inv_m, false);  // mu (n) = x^T 1 / m
+  else
+    drv.a_times(ta, ones, mu, inv_m);          // tall view = x^T (n x m): mu (n) = x^T 1 / m
+  // centred copy (center_mat_col clones too, mat_utils.rs:484): memory rows/cols of the staged operand
+  const int64_t ldp = round_up(ta.mem.cols, kLdPad);
+  T* cbuf = (T*)dev.alloc_bytes((size_t)ta.mem.rows * (size_t)ldp * sizeof(T));
+  dev.memset_zero(cbuf, (size_t)ta.mem.rows * (size_t)ldp * sizeof(T));
+  // data columns run along the memory columns iff (tall & row-major) or (fat & column-major-as-rows ...):
+  // tall view element (i, j): row-major memory (i, j), else memory (j, i).  Data column index of x is j for
+  // the tall case and i for the fat case.
+  const bool mean_along_mem_cols = (ta.row_major != fat);
+  dev.center_rows_cols(ta.mem.p, ta.mem.rows, ta.mem.cols, ta.mem.ld, mu.p, mean_along_mem_cols, cbuf, ldp);
+  TallA<T> tc = ta;
+  tc.mem.p = cbuf;
+  tc.mem.ld = ldp;
+  tc.mem.cols_readable = ldp;
+  const int64_t k = rank;
+  const int64_t l = std::min<int64_t>(rank + n_oversamples, tc.nt);
+  if (ro.omega && ro.omega_ld < tc.nt) throw Error(ST_EINVAL, "omega_ld < min(m, n)");
+  Skinny<T> ut = dev.template alloc_skinny<T>(tc.mt, k);
+  Skinny<T> vtall = dev.template alloc_skinny<T>(tc.nt, k);
+  T* s_dev = dev.template alloc_scalar<T>((int)k);
+  drv.random_svd_tall(tc, k, l, n_iter, ro, ut, s_dev, vtall);
+  // components_ = vr = V^T (k x n_dim)   pca_rsvd.rs:70-71
+  if (!fat)
+    dev.copy_out(vtall, k, comps, ldc, /*transpose=*/true, host_ptrs);
+  else
+    dev.copy_out(ut, k, comps, ldc, true, host_ptrs);
+  dev.copy_values_out(s_dev, k, s, host_ptrs);
+  dev.copy_values_out(mu.p, n, means, host_ptrs);
+  dev.end_call();
+  if (tm_out) *tm_out = drv.tm;
+}
+
 template <class Dev, class T>
 inline void power_iter_entry(Dev& dev, bool host_ptrs, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,
                              int64_t width, int64_t n_iter, const corrla_opts* opts, T* q, int64_t ldq) {

@@ -432,6 +432,21 @@ class HipDev {
     CORRLA_HIP(hipGetLastError());
   }
 
+  template <class T>
+  void fill_const(T* p, int64_t n, T v) {
+    const int blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (n + 255) / 256));
+    hipLaunchKernelGGL((k::fill_const_kernel<T>), dim3(blocks), dim3(256), 0, stream, p, n, v);
+    CORRLA_HIP(hipGetLastError());
+  }
+  template <class T>
+  void center_rows_cols(const T* in, int64_t rows, int64_t cols, int64_t ldi, const T* mu, bool along_cols, T* out,
+                        int64_t ldo) {
+    dim3 grid((unsigned)((cols + 255) / 256), (unsigned)std::min<int64_t>(rows, 4096));
+    hipLaunchKernelGGL((k::center_kernel<T>), grid, dim3(256), 0, stream, in, rows, cols, ldi, mu, along_cols ? 1 : 0, out,
+                       ldo);
+    CORRLA_HIP(hipGetLastError());
+  }
+
   // ---- elementwise / reductions ------------------------------------------------------------
   template <class T>
   void sumsq(const Skinny<T>& y, double* out_dev) {

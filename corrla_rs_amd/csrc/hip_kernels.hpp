@@ -1280,6 +1280,24 @@ __global__ void series_combine_kernel(const T* e1, const T* e2, const T* e3, int
   m[(int64_t)j * ldm + i] = (i == j ? (T)1 : (T)0) - (T)0.5 * e1[o] + (T)0.375 * e2[o] - (T)0.3125 * e3[o];
 }
 
+// ---- PCA caller: centring (center_mat_col, mat_utils.rs:482-502) -----------------------------------
+template <class T>
+__global__ void fill_const_kernel(T* p, int64_t n, T v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+// out[r][c] = in[r][c] - (along_cols ? mu[c] : mu[r]); row-major in/out with leading dimensions ldi / ldo
+template <class T>
+__global__ void center_kernel(const T* in, int64_t rows, int64_t cols, int64_t ldi, const T* mu, int along_cols, T* out,
+                              int64_t ldo) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const T mc = along_cols ? mu[c] : (T)0;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const T m_ = along_cols ? mc : mu[r];
+    out[r * ldo + c] = in[r * ldi + c] - m_;
+  }
+}
+
 // ---- layout helpers --------------------------------------------------------------------------
 // dst[r * ldd + c] = src[r * rs + c * cs]   (repack any strided matrix to padded row-major)
 template <class T>

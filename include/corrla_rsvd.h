@@ -124,6 +124,33 @@ CORRLA_API corrla_status corrla_rsvd_dev_f64(corrla_ctx* ctx, const double* a, i
                                   int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
                                   const corrla_opts* opts, double* u, int64_t ldu, double* s, double* vt, int64_t ldvt);
 
+/* ---- PCA caller ---------------------------------------------------
+ * Replaces  PcaRsvd::new(x_mat, rank)                           src/lib_math_utils/pca_rsvd.rs:56-82
+ *   means = mat_mean(x, 1); cx = center_mat_col(x); (_, s, vt) = random_svd(cx, rank, n_iter, n_oversamples)
+ * and pyo3  rpca(a, n_rank, n_iters, n_oversamples)             src/lib_math_utils_py.rs:38-55
+ * The reference hard-codes n_iter = 20, n_oversamples = min(n, 10) (pca_rsvd.rs:65-66; rpca ignores its last two
+ * arguments); this ABI takes them explicitly and the Rust / Python shims pass the reference's values.
+ * x: n_samples x n_dim, strided like a MatRef.  Outputs: means (n_dim values), s (rank values, the k x 1
+ * column), components (rank x n_dim, column-major, leading dimension ldc >= rank).  The centred matrix is
+ * formed on the device (one extra read + write of x); the columns' means come from the same MFMA kernel as
+ * A^T Y.  Host-pointer and device-pointer variants. */
+CORRLA_API corrla_status corrla_pca_f32(corrla_ctx* ctx, const float* x, int64_t n_samples, int64_t n_dim,
+                                        int64_t row_stride, int64_t col_stride, int64_t rank, int64_t n_iter,
+                                        int64_t n_oversamples, const corrla_opts* opts, float* means, float* s,
+                                        float* components, int64_t ldc);
+CORRLA_API corrla_status corrla_pca_f64(corrla_ctx* ctx, const double* x, int64_t n_samples, int64_t n_dim,
+                                        int64_t row_stride, int64_t col_stride, int64_t rank, int64_t n_iter,
+                                        int64_t n_oversamples, const corrla_opts* opts, double* means, double* s,
+                                        double* components, int64_t ldc);
+CORRLA_API corrla_status corrla_pca_dev_f32(corrla_ctx* ctx, const float* x, int64_t n_samples, int64_t n_dim,
+                                            int64_t row_stride, int64_t col_stride, int64_t rank, int64_t n_iter,
+                                            int64_t n_oversamples, const corrla_opts* opts, float* means, float* s,
+                                            float* components, int64_t ldc);
+CORRLA_API corrla_status corrla_pca_dev_f64(corrla_ctx* ctx, const double* x, int64_t n_samples, int64_t n_dim,
+                                            int64_t row_stride, int64_t col_stride, int64_t rank, int64_t n_iter,
+                                            int64_t n_oversamples, const corrla_opts* opts, double* means, double* s,
+                                            double* components, int64_t ldc);
+
 /* ---- the range finder: power_iter ---------------------------------------------------
  * Replaces  pub fn power_iter<T>(a_mat: MatRef<T>, omega_rank, n_iter) -> Mat<T>
  *                                                              src/lib_math_utils/random_svd.rs:15-59

@@ -35,6 +35,7 @@ __all__ = [
     "power_iter",
     "random_svd",
     "rsvd",
+    "pca_rsvd",
     "relerr",
     "algorithmic_flops",
     "KNOWN_ANSWER_A",
@@ -130,6 +131,20 @@ def rsvd(a_mat: np.ndarray, n_rank: int, n_iters: int, n_oversamples: int, omega
     (k x 1)."""
     a = np.asarray(a_mat, dtype=np.float64)
     return random_svd(a, n_rank, n_iters, n_oversamples, omega=omega)
+
+
+def pca_rsvd(x_mat: np.ndarray, rank: int, omega=None):
+    """``PcaRsvd::new(x_mat, rank)`` (src/lib_math_utils/pca_rsvd.rs:56-82): column means (mat_mean axis 1,
+    mat_utils.rs:87-119), centred copy (center_mat_col, mat_utils.rs:482-502), then
+    ``random_svd(cx, rank, 20, min(n_dim, 10))`` (pca_rsvd.rs:65-66).  Returns (means 1 x n, singular values
+    k x 1, components k x n, explained variance k x 1 = s^2 / (n_samples - 1), pca_rsvd.rs:91-99).
+    This is also what pyo3 ``rpca`` returns (it ignores its n_iters / n_oversamples, lib_math_utils_py.rs:39,48)."""
+    x = np.asarray(x_mat, dtype=np.float64)
+    n_samples, n_dim = x.shape
+    means = x.mean(axis=0, keepdims=True)
+    cx = x - means
+    _u, s, vt = random_svd(cx, rank, 20, min(n_dim, 10), omega=omega)
+    return means, s, vt, s * s / (n_samples - 1.0)
 
 
 def relerr(a: np.ndarray, u: np.ndarray, s: np.ndarray, vt: np.ndarray) -> float:

@@ -201,6 +201,16 @@ class EmuDev {
       for (int64_t c = 0; c < cols; ++c) dst[r * ldd + c] = src[r * rs + c * cs];
   }
   template <class T>
+  void fill_const(T* p, int64_t n, T v) {
+    for (int64_t i = 0; i < n; ++i) p[i] = v;
+  }
+  template <class T>
+  void center_rows_cols(const T* in, int64_t rows, int64_t cols, int64_t ldi, const T* mu, bool along_cols, T* out,
+                        int64_t ldo) {
+    for (int64_t r = 0; r < rows; ++r)
+      for (int64_t c = 0; c < cols; ++c) out[r * ldo + c] = in[r * ldi + c] - (along_cols ? mu[c] : mu[r]);
+  }
+  template <class T>
   void sumsq(const Skinny<T>& y, double* out) {
     double s = 0.0;
     for (int64_t i = 0; i < y.ld * y.cols_alloc; ++i) s += (double)y.p[i] * (double)y.p[i];
@@ -244,6 +254,14 @@ EMU_API void corrla_emu_set_comm(emu_allreduce_fn fn, int nranks) {
       EmuDev dev;                                                                                                      \
       rsvd_entry<EmuDev, T>(dev, true, true, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt, nullptr,        \
                             false);                                                                                    \
+    });                                                                                                                \
+  }                                                                                                                    \
+  EMU_API int corrla_emu_pca_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank,             \
+                                   int64_t n_iter, int64_t p, const corrla_opts* o, T* means, T* s, T* comps,          \
+                                   int64_t ldc) {                                                                      \
+    return guarded([&] {                                                                                               \
+      EmuDev dev;                                                                                                      \
+      pca_entry<EmuDev, T>(dev, true, a, m, n, rs, cs, rank, n_iter, p, o, means, s, comps, ldc, nullptr, false);      \
     });                                                                                                                \
   }                                                                                                                    \
   EMU_API int corrla_emu_power_iter_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t width,             \

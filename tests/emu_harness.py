@@ -118,3 +118,24 @@ def emu_fill_normal(rows, cols, seed, dtype=np.float64, row0=0, global_cols=None
                                                      C.c_uint64(seed), i64(row0), i64(global_cols or cols))
     assert rc == 0
     return out
+
+
+def emu_pca(x, rank, q, p, omega=None):
+    e = emu()
+    x = np.asarray(x)
+    suf = "f32" if x.dtype == np.float32 else "f64"
+    m, n = x.shape
+    rs, cs = x.strides[0] // x.itemsize, x.strides[1] // x.itemsize
+    nt = min(m, n)
+    l = min(rank + p, nt)
+    o, keep = _opts(omega, nt, l, x.dtype)
+    means = np.empty((1, n), dtype=x.dtype)
+    s = np.empty((rank, 1), dtype=x.dtype)
+    comps = np.empty((rank, n), dtype=x.dtype, order="F")
+    i64 = C.c_int64
+    rc = getattr(e, "corrla_emu_pca_" + suf)(C.c_void_p(x.ctypes.data), i64(m), i64(n), i64(rs), i64(cs), i64(rank), i64(q),
+                                             i64(p), C.byref(o) if o is not None else None, C.c_void_p(means.ctypes.data),
+                                             C.c_void_p(s.ctypes.data), C.c_void_p(comps.ctypes.data), i64(rank))
+    if rc != 0:
+        raise (ValueError if rc == 1 else RuntimeError)(e.corrla_emu_last_error().decode())
+    return means, s, comps

@@ -7,7 +7,7 @@ import pytest
 
 from oracle import rsvd_oracle as orc
 from tests.conftest import golden_names
-from tests.emu_harness import emu, emu_fill_normal, emu_matmul, emu_power_iter, emu_rsvd
+from tests.emu_harness import emu, emu_fill_normal, emu_matmul, emu_pca, emu_power_iter, emu_rsvd
 from tests.helpers import align_signs, check_factorization, load_golden, orth_err
 
 
@@ -161,3 +161,26 @@ def test_fill_normal_is_counter_based_and_standard_normal():
     from scipy import stats
     assert stats.kstest(big.ravel()[:50000], "norm").pvalue > 1e-3
     assert not np.array_equal(emu_fill_normal(8, 8, seed=1), emu_fill_normal(8, 8, seed=2))
+
+
+@pytest.mark.parametrize("shape", [(100, 10), (60, 90), (300, 40)])
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_emu_pca_matches_oracle(shape, order):
+    """PcaRsvd::new (pca_rsvd.rs:56-82) through the real glue: means, centring, random_svd(cx, k, 20, min(n,10))."""
+    rng = np.random.default_rng(sum(shape))
+    m, n = shape
+    x = rng.standard_normal((m, n)) * (0.8 ** np.arange(n)) + rng.standard_normal((1, n)) * 3.0
+    x = np.asfortranarray(x) if order == "F" else np.ascontiguousarray(x)
+    k = 4
+    p = min(n, 10)
+    nt = min(m, n)
+    omega = rng.standard_normal((nt, min(k + p, nt)))
+    means, s, comps = emu_pca(x, k, 20, p, omega=omega)
+    mo, so, co, ev = orc.pca_rsvd(x, k, omega=omega)
+    assert np.allclose(means, mo, atol=1e-12)
+    assert np.allclose(s, so, rtol=1e-9)
+    proj, projo = comps.T @ comps, co.T @ co   # sign-free comparison of the component subspace
+    assert np.linalg.norm(proj - projo) < 1e-7
+    # explained variance matches the eigenvalues of the sample covariance (what PCA means)
+    cov_eigs = np.sort(np.linalg.eigvalsh(np.cov(x, rowvar=False)))[::-1][:k]
+    assert np.allclose((s * s / (m - 1.0)).ravel(), cov_eigs, rtol=1e-6)

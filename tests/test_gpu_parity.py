@@ -360,3 +360,56 @@ def test_large_norm_does_not_overflow_f32(ctx):
     assert np.all(np.isfinite(s)) and np.all(np.isfinite(u)) and np.all(np.isfinite(vt))
     ex = np.linalg.svd(a.astype(np.float64), compute_uv=False)[:6]
     assert np.allclose(s.ravel(), ex, rtol=0.15)
+
+
+# ---- PCA caller (pca_rsvd.rs:56-82, pyo3 rpca) --------------------------------
+@pytest.mark.parametrize("shape", [(100, 10), (2000, 64), (50, 400)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pca_matches_oracle_and_sklearn(ctx, shape, dtype):
+    rng = np.random.default_rng(sum(shape))
+    m, n = shape
+    x = (rng.standard_normal((m, n)) * (0.85 ** np.arange(n)) + rng.standard_normal((1, n)) * 3.0).astype(dtype)
+    k = 4
+    p = min(n, 10)
+    nt = min(m, n)
+    omega = rng.standard_normal((nt, min(k + p, nt))).astype(dtype)
+    means, s, comps = ctx.pca(x, k, omega=omega)
+    mo, so, co, evo = orc.pca_rsvd(x.astype(np.float64), k, omega=omega.astype(np.float64))
+    f64 = dtype == np.float64
+    assert means.shape == (1, n) and s.shape == (k, 1) and comps.shape == (k, n)
+    assert np.allclose(means, mo, atol=1e-12 if f64 else 1e-5)
+    assert np.allclose(s, so, rtol=1e-9 if f64 else 1e-4)
+    assert np.linalg.norm(comps.T.astype(np.float64) @ comps - co.T @ co) < (1e-7 if f64 else 2e-3)
+    from sklearn.decomposition import PCA
+    sk = PCA(n_components=k, svd_solver="full").fit(x.astype(np.float64))
+    assert np.allclose((s.astype(np.float64) ** 2 / (m - 1.0)).ravel(), sk.explained_variance_, rtol=1e-6 if f64 else 1e-3)
+
+
+def test_rpca_surface_ignores_iters_and_oversamples_like_the_reference(ctx):
+    # lib_math_utils_py.rs:38-55: rpca(a, n_rank, n_iters, n_oversamples) -> (singular_values (k,1), components (k,n))
+    import corrla_rs as hrl
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((500, 12)) * np.arange(1, 13)
+    sv, pc = hrl.rpca(x, 3, 1, 0, seed=7)
+    sv2, pc2 = hrl.rpca(x, 3, 99, 5, seed=7)
+    assert sv.shape == (3, 1) and pc.shape == (3, 12)
+    assert np.array_equal(sv, sv2) and np.array_equal(pc, pc2)
+    pca = hrl.PcaRsvd(x, 3, seed=7)
+    assert np.allclose(pca.explained_var().ravel(), np.sort(np.linalg.eigvalsh(np.cov(x, rowvar=False)))[::-1][:3], rtol=1e-6)
+    red = pca.apply_tr(x)
+    assert red.shape == (500, 3)
+    back = pca.apply_inv_tr(red)
+    # rank-3 reconstruction of 12-d data equals the optimal (exact PCA) rank-3 residual
+    xc = x - x.mean(axis=0)
+    opt = np.sqrt(np.sum(np.linalg.svd(xc, compute_uv=False)[3:] ** 2))
+    assert abs(np.linalg.norm(back - x) - opt) <= 1e-6 * opt
+
+
+def test_pca_device_tensor_path(ctx, torch):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((4096, 256), dtype=torch.float32, device="cuda", generator=g) * torch.linspace(3, 0.1, 256, device="cuda")
+    means, s, comps = ctx.pca(x, 8, seed=5)
+    xs = x.double()
+    ev = torch.linalg.eigvalsh(torch.cov(xs.t())).flip(0)[:8]
+    assert torch.allclose((s.double() ** 2 / (4096 - 1)).ravel(), ev, rtol=2e-3)
+    assert torch.allclose(means.double().ravel(), xs.mean(dim=0), atol=1e-5)
