@@ -413,3 +413,44 @@ def test_pca_device_tensor_path(ctx, torch):
     ev = torch.linalg.eigvalsh(torch.cov(xs.t())).flip(0)[:8]
     assert torch.allclose((s.double() ** 2 / (4096 - 1)).ravel(), ev, rtol=2e-3)
     assert torch.allclose(means.double().ravel(), xs.mean(dim=0), atol=1e-5)
+
+
+# ---- callers on the path: POD modes, active-subspace fit_svd, DMDc ------
+@pytest.mark.parametrize("nx,nt", [(20, 40), (50, 40), (500, 40)])
+def test_dmdc_reference_test_on_gpu(ctx, nx, nt):
+    """The reference's own test_dmdc (dmd_rom.rs:233-310) through the GPU RSVD: shapes, 14 eigenvalues, and the
+    20-step prediction within 5e-2 of the truth."""
+    import corrla_rs_amd as cr
+    from oracle import callers_oracle as co
+    snaps, u = co.dmdc_reference_test_data(nx, nt)
+    m = cr.DMDc(snaps, u, 1.0, 14, 40, seed=3, ctx=ctx)
+    assert m.est_a_til().shape == (nx, nx) and m.est_b_til().shape[0] == nx
+    assert m.lambdas.shape[0] == 14
+    pred = m.predict_multiple(snaps[:, 0:1], u)
+    assert np.max(np.abs(pred[:, 19] - snaps[:, 20])) < 5e-2
+    # and against the oracle's DMDc with shared sketches: the same one-step operators on the data
+    rng = np.random.default_rng(nx)
+    lx = min(14 + 12, min(nx + 1, nt - 1))
+    ly = min(14 + 12, min(nx, nt - 1))
+    om_x = rng.standard_normal((min(nx + 1, nt - 1), lx))
+    om_y = rng.standard_normal((min(nx, nt - 1), ly))
+    mg = cr.DMDc(snaps, u, 1.0, 14, 40, omega_x=om_x, omega_y=om_y, ctx=ctx)
+    mo = co.DMDcOracle(snaps, u, 1.0, 14, 40, omega_x=om_x, omega_y=om_y)
+    pg, po = mg.predict_multiple(snaps[:, 0:1], u), mo.predict_multiple(snaps[:, 0:1], u)
+    assert np.max(np.abs(pg[:, :20] - po[:, :20])) < 5e-2 * np.max(np.abs(po[:, :20]))
+
+
+def test_pod_modes_and_active_ss_fit_svd(ctx):
+    import corrla_rs_amd as cr
+    from oracle import callers_oracle as co
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((20, 6)) * [10, 7, 5, 1e-2, 1e-3, 1e-4]) @ rng.standard_normal((6, 5000))
+    om = rng.standard_normal((20, 13))
+    mg, mo = cr.pod_modes(x, 3, omega=om, ctx=ctx), co.pod_modes(x, 3, omega=om)   # benchmark_pod.py shape: 20 x 5000
+    assert mg.shape == (5000, 3) and np.linalg.norm(mg @ mg.T @ mo - mo) < 1e-8
+    g = (rng.standard_normal((8, 8)) * [5, 3, 2, 1, .1, .01, .001, .0001]) @ rng.standard_normal((8, 4000))
+    om2 = rng.standard_normal((8, 8))
+    ug, sg = cr.active_ss_fit_svd(g, 4, omega=om2, ctx=ctx)
+    uo, so = co.active_ss_fit_svd(g, 4, omega=om2)
+    assert np.allclose(np.diag(sg), np.diag(so), rtol=1e-9)
+    assert np.linalg.norm(ug @ ug.T - uo @ uo.T) < 1e-7
