@@ -57,13 +57,42 @@ def cpu_baseline(a_dev, l):
     with threadpool_limits(limits=threads):
         orc.random_svd(a[:1024, :1024], RANK, N_ITER, N_OVER, omega=omega[:1024])  # warm the BLAS threads
         t0 = time.perf_counter()
-        orc.random_svd(a, RANK, N_ITER, N_OVER, omega=omega)
+        uo, so, vto = orc.random_svd(a, RANK, N_ITER, N_OVER, omega=omega)
         dt = time.perf_counter() - t0
     flops = orc.algorithmic_flops(s, s, RANK, N_ITER, N_OVER)
-    return {"value": round(flops / dt / 1e9, 2), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+    base = {"value": round(flops / dt / 1e9, 2), "unit": "GFLOP/s", "cores": threads, "kind": "port",
             "sample": f"oracle/rsvd_oracle.py random_svd (numpy restatement of random_svd.rs:15-110) on the {s}x{s} f32 "
                       f"matrix of the same workload, rank {RANK}, q={N_ITER}, p={N_OVER}: {dt:.2f} s on {threads} "
                       f"OpenBLAS threads ({avail} logical CPUs visible)"}
+    return base, (a, omega, uo, so, vto)
+
+
+def relerr_device(torch, a_dev, u, s, vt):
+    """||A - U diag(S) Vt||_F / ||A||_F accumulated in f64, row blocks on the device (checker, untimed)."""
+    num = den = 0.0
+    us = u.double() * s.double().ravel()
+    vtd = vt.double()
+    for r0 in range(0, a_dev.shape[0], 2048):
+        blk = a_dev[r0:r0 + 2048].double()
+        num += float(((blk - us[r0:r0 + 2048] @ vtd) ** 2).sum().item())
+        den += float((blk ** 2).sum().item())
+    return (num / den) ** 0.5
+
+
+def accuracy_gate(torch, ctx, a_dev, cpu_pack):
+    """North-star parity at the full benchmark size: same A, same Omega, GPU path vs the CPU restatement."""
+    a_host, omega, uo, so, vto = cpu_pack
+    if a_host.shape != tuple(a_dev.shape):
+        return None
+    u, s, vt = ctx.rsvd(a_dev, RANK, N_ITER, N_OVER, omega=omega)
+    re_gpu = relerr_device(torch, a_dev, u, s, vt)
+    dev = a_dev.device
+    re_cpu = relerr_device(torch, a_dev, torch.as_tensor(uo, device=dev), torch.as_tensor(so, device=dev),
+                           torch.as_tensor(vto, device=dev))
+    ds = float((s.double().ravel().cpu() - torch.as_tensor(so).double().ravel()).abs().max().item()) / float(so[0, 0])
+    return {"relerr_gpu": re_gpu, "relerr_cpu_restatement": re_cpu, "abs_diff": abs(re_gpu - re_cpu),
+            "gate_abs_diff": 1e-5, "passed": bool(abs(re_gpu - re_cpu) <= 1e-5), "max_abs_dS_over_s1": ds,
+            "same_A_same_Omega": True}
 
 
 def main():
@@ -187,7 +216,9 @@ def main():
             "phases_ms_last_step": {k_: (round(v, 3) if isinstance(v, float) else v) for k_, v in tm.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(a, l)
+            result["cpu_baseline"], pack = cpu_baseline(a, l)
+            result["accuracy"] = accuracy_gate(torch, ctx, a, pack)
+            log(f"[bench] accuracy gate (same A, same Omega): {json.dumps(result['accuracy'])}")
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)

@@ -454,3 +454,18 @@ def test_pod_modes_and_active_ss_fit_svd(ctx):
     uo, so = co.active_ss_fit_svd(g, 4, omega=om2)
     assert np.allclose(np.diag(sg), np.diag(so), rtol=1e-9)
     assert np.linalg.norm(ug @ ug.T - uo @ uo.T) < 1e-7
+
+
+def test_sharded_entry_point_with_world_size_1_rccl(torch):
+    """The row-sharded entry point with a real RCCL communicator of one rank equals the plain entry point
+    (the N > 1 exchange logic is covered by tests/test_sharded_gloo.py through the same driver)."""
+    import corrla_rs_amd as cr
+    c = cr.Context(0)
+    c.comm_init(cr.Context.unique_id(), 0, 1)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.randn((3000, 200), dtype=torch.float32, device="cuda", generator=g)
+    om = np.random.default_rng(2).standard_normal((200, 26)).astype(np.float32)
+    u1, s1, vt1 = c.rsvd_sharded(a, 16, 4, 10, omega=om)
+    u0, s0, vt0 = c.rsvd(a, 16, 4, 10, omega=om)
+    assert torch.equal(s0, s1) and torch.equal(u0, u1) and torch.equal(vt0, vt1)
+    c.close()
