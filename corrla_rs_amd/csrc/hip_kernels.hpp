@@ -653,6 +653,27 @@ __global__ void fill_normal_kernel(T* p, int64_t rows, int64_t cols, int64_t rs,
 // C = U_c diag(sigma) V_c^T.  The kernel sorts sigma descending and writes sigma[:k], V_c[:, :k]
 // (-> m1) and U_c[:, :k] (-> m2) directly into the zero-padded skinny operands of the GEMMs that
 // follow (U = Q * m1, V = Qb * m2), so the final stage needs no host round trip.
+// Sum over a G-lane group (G = 8 or 16, groups aligned to G lanes), result in every lane.  f32 uses DPP
+// (quad_perm xor-1 / xor-2, row_half_mirror, row_mirror) on the VALU; __shfl_xor would go through the LDS
+// crossbar (ds_bpermute), which the Jacobi kernels cannot afford.  f64 keeps the shuffles.
+template <int G>
+__device__ __forceinline__ float group_sum(float x) {
+  static_assert(G == 8 || G == 16, "group size");
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  x += dpp(x, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+  x += dpp(x, std::integral_constant<int, 0x141>{});  // row_half_mirror: lane i <-> 7 - i
+  if constexpr (G == 16) x += dpp(x, std::integral_constant<int, 0x140>{});  // row_mirror: lane i <-> 15 - i
+  return x;
+}
+template <int G>
+__device__ __forceinline__ double group_sum(double x) {
+#pragma unroll
+  for (int msk = 1; msk < G; msk <<= 1) x += __shfl_xor(x, msk, G);
+  return x;
+}
 // Jacobi rotation (cos, sin) that annihilates the off-diagonal g of [[a, g], [g, b]]; `rel` receives
 // |g| / sqrt(a b).  f32 uses the single-instruction reciprocal / rsqrt (~1 ulp; the Jacobi kernels are
 // VALU-issue bound and the IEEE sqrt/div sequences were ~1/4 of their instruction stream); f64 stays IEEE.
@@ -773,12 +794,9 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
             b += y[e][z] * y[e][z];
             g += x[e][z] * y[e][z];
           }
-#pragma unroll
-        for (int msk = 1; msk < G; msk <<= 1) {
-          a += __shfl_xor(a, msk, G);
-          b += __shfl_xor(b, msk, G);
-          g += __shfl_xor(g, msk, G);
-        }
+        a = group_sum<G>(a);
+        b = group_sum<G>(b);
+        g = group_sum<G>(g);
         T cs, sn, rel;
         if (jacobi_rotation(a, b, g, tol, cs, sn, rel)) {
 #pragma unroll
@@ -937,12 +955,9 @@ __global__ __launch_bounds__(1024) void jacobi_svd_split_kernel(const T* __restr
                 b += y[e][z] * y[e][z];
                 g += x[e][z] * y[e][z];
               }
-#pragma unroll
-            for (int msk = 1; msk < GW; msk <<= 1) {
-              a += __shfl_xor(a, msk, GW);
-              b += __shfl_xor(b, msk, GW);
-              g += __shfl_xor(g, msk, GW);
-            }
+            a = group_sum<GW>(a);
+            b = group_sum<GW>(b);
+            g = group_sum<GW>(g);
             T rel;
             if (jacobi_rotation(a, b, g, tol, cs, sn, rel)) {
 #pragma unroll
