@@ -327,11 +327,11 @@ class HipDev {
                        ld, cols_pad, rows_pad, ctl);
     const double eps = (double)std::numeric_limits<T>::epsilon();
     const float tol_early = (float)std::sqrt(eps);
-    const size_t lds = (size_t)(2 * 16 * (rows_pad + 1) + 3 * 16 * 17 + 32) * sizeof(T) + 16 * sizeof(int) + 64;
+    const size_t lds = (size_t)(2 * 16 * (rows_pad + 1) + 7 * 16 * 17 + 32) * sizeof(T) + 16 * sizeof(int) + 64;
     const int max_sweeps = env_int("CORRLA_JACOBI_SWEEPS", 12), inner = env_int("CORRLA_JACOBI_INNER", 1);
     for (int sw = 0; sw < max_sweeps; ++sw) {
       for (int round = 0; round < nb - 1; ++round)
-        hipLaunchKernelGGL((k::jacobi_block_round_kernel<T>), dim3(nb / 2), dim3(64), lds, stream, wj, ld, vj, ld, rows_pad,
+        hipLaunchKernelGGL((k::jacobi_block_round_kernel<T>), dim3(nb / 2), dim3(256), lds, stream, wj, ld, vj, ld, rows_pad,
                            nb, round, inner, ctl);
       hipLaunchKernelGGL(k::jacobi_sweep_end_kernel, dim3(1), dim3(1), 0, stream, ctl, tol_early);
     }

@@ -1066,8 +1066,8 @@ struct JacobiCtl {
 };
 
 template <class T>
-__global__ __launch_bounds__(64) void jacobi_block_round_kernel(T* w, int64_t ldw, T* v, int64_t ldv, int rows_pad, int nb,
-                                                                int round, int inner_sweeps, JacobiCtl* ctl) {
+__global__ __launch_bounds__(256) void jacobi_block_round_kernel(T* w, int64_t ldw, T* v, int64_t ldv, int rows_pad, int nb,
+                                                                 int round, int inner_sweeps, JacobiCtl* ctl) {
   typedef typename MT<T>::acc_t acc_t;
   if (ctl->done) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1077,127 +1077,113 @@ __global__ __launch_bounds__(64) void jacobi_block_round_kernel(T* w, int64_t ld
   T* gm = vt + 16 * LP;      // [16][17]
   T* g2 = gm + 16 * 17;      // [16][17]
   T* jm = g2 + 16 * 17;      // [16][17]
-  T* alpha = jm + 16 * 17;   // [16]
-  T* beta = alpha + 16;      // [16]
+  T* gpart = jm + 16 * 17;   // [4][16][17] partial Grams of the 4 waves
+  T* alpha = gpart + 4 * 16 * 17;  // [16]
+  T* beta = alpha + 16;            // [16]
   int* part = (int*)(beta + 16);
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int x = lane & 15, kq = lane >> 4;
   // block pair of this workgroup
   int bi, bj;
-  {
-    const int pr = blockIdx.x, n = nb;
-    if (pr == 0) {
-      bi = n - 1;
-      bj = round;
-    } else {
-      bi = (round + pr) % (n - 1);
-      bj = (round - pr + (n - 1)) % (n - 1);
-    }
-    if (bi > bj) {
-      const int t_ = bi;
-      bi = bj;
-      bj = t_;
-    }
-  }
+  tournament_pair(nb, round, blockIdx.x, bi, bj);
   auto gcol = [&](int c) { return (c < 8) ? bi * 8 + c : bj * 8 + (c - 8); };
-  // 1. stage
-  for (int e = lane; e < 16 * rows_pad; e += 64) {
+  // 1. stage the 16 columns of W and V (all 4 waves)
+  for (int e = tid; e < 16 * rows_pad; e += 256) {
     const int c = e / rows_pad, r = e - c * rows_pad;
     const int64_t gc = gcol(c);
     wt[c * LP + r] = w[gc * ldw + r];
     vt[c * LP + r] = v[gc * ldv + r];
   }
   __syncthreads();
-  // 2. Gram
-  acc_t acc = (acc_t){0, 0, 0, 0};
-  for (int it = 0; it < rows_pad / 16; ++it) {
+  // 2. Gram: wave `wave` sums the 16-row groups it = wave, wave + 4, ... (independent MFMA chains per wave)
+  const int nit = rows_pad / 16;
+  {
+    acc_t acc = (acc_t){0, 0, 0, 0};
+    for (int it = wave; it < nit; it += 4) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const T a = wt[x * LP + 16 * it + 4 * kq + j];
-      acc = MT<T>::mma(a, a, acc);
+      for (int j = 0; j < 4; ++j) {
+        const T a = wt[x * LP + 16 * it + 4 * kq + j];
+        acc = MT<T>::mma(a, a, acc);
+      }
     }
-  }
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int r = MT<T>::drow(lane, jj);
-    gm[r * 17 + x] = acc[jj];
-    jm[r * 17 + x] = (r == x) ? (T)1 : (T)0;
+    for (int jj = 0; jj < 4; ++jj) gpart[(wave * 16 + MT<T>::drow(lane, jj)) * 17 + x] = acc[jj];
   }
   __syncthreads();
-  // convergence measure of this block pair
   {
-    float mx = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int r = MT<T>::drow(lane, jj);
-      if (r != x) {
-        const T d = gm[r * 17 + r] * gm[x * 17 + x];
-        if (d > (T)0) mx = fmaxf(mx, (float)(fabs(gm[r * 17 + x]) / sqrt(d)));
-      }
-    }
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
-    if (lane == 0) atomicMax(&ctl->max_bits, __float_as_uint(mx));
+    const int r = tid >> 4, cx = tid & 15;  // 256 threads = 16 x 16 entries
+    const T gsum = gpart[(0 * 16 + r) * 17 + cx] + gpart[(1 * 16 + r) * 17 + cx] + gpart[(2 * 16 + r) * 17 + cx] +
+                   gpart[(3 * 16 + r) * 17 + cx];
+    gm[r * 17 + cx] = gsum;
+    jm[r * 17 + cx] = (r == cx) ? (T)1 : (T)0;
   }
-  // 3. two-sided Jacobi on G, accumulating J
-  const T tiny = (T)4 * (T)(sizeof(T) == 4 ? 1.1920929e-07 : 2.220446049250313e-16);
-  for (int sw = 0; sw < inner_sweeps; ++sw) {
-    for (int step = 0; step < 15; ++step) {
-      if (lane < 8) {
-        int p, q;
-        if (lane == 0) {
-          p = 15;
-          q = step;
-        } else {
-          p = (step + lane) % 15;
-          q = (step - lane + 15) % 15;
-        }
-        if (p > q) {
-          const int t_ = p;
-          p = q;
-          q = t_;
-        }
-        const T a = gm[p * 17 + p], b = gm[q * 17 + q], g = gm[p * 17 + q];
-        T cs = (T)1, sn = (T)0;
-        const T ab = sqrt(a * b);
-        if (ab > (T)0 && fabs(g) > tiny * ab) {
-          const T zeta = (b - a) / ((T)2 * g);
-          const T t = (zeta >= (T)0 ? (T)1 : (T)-1) / (fabs(zeta) + sqrt((T)1 + zeta * zeta));
-          cs = (T)1 / sqrt((T)1 + t * t);
-          sn = cs * t;
-        }
-        alpha[p] = cs;
-        beta[p] = -sn;
-        part[p] = q;
-        alpha[q] = cs;
-        beta[q] = sn;
-        part[q] = p;
-      }
-      __syncthreads();
-      // column pass: G2 = G R, J <- J R
-      T jn[4];
+  __syncthreads();
+  // 3. inner two-sided Jacobi on the 16 x 16 Gram, wave 0 only (the others wait at the barrier below)
+  if (wave == 0) {
+    {  // convergence measure of this block pair (before rotating)
+      float mx = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int idx = lane + 64 * e, r = idx >> 4, cx = idx & 15, pc = part[cx];
-        g2[r * 17 + cx] = alpha[cx] * gm[r * 17 + cx] + beta[cx] * gm[r * 17 + pc];
-        jn[e] = alpha[cx] * jm[r * 17 + cx] + beta[cx] * jm[r * 17 + pc];
+        const int idx = lane + 64 * e, r = idx >> 4, cx = idx & 15;
+        if (r != cx) {
+          const T d = gm[r * 17 + r] * gm[cx * 17 + cx];
+          if (d > (T)0) mx = fmaxf(mx, (float)(fabs(gm[r * 17 + cx]) / sqrt(d)));
+        }
       }
-      __syncthreads();
-      // row pass: G = R^T G2
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+      if (lane == 0) atomicMax(&ctl->max_bits, __float_as_uint(mx));
+    }
+    const T tiny = (T)4 * (T)(sizeof(T) == 4 ? 1.1920929e-07 : 2.220446049250313e-16);
+    for (int sw = 0; sw < inner_sweeps; ++sw) {
+      for (int step = 0; step < 15; ++step) {
+        if (lane < 8) {
+          int p, q;
+          tournament_pair(16, step, lane, p, q);
+          T cs = (T)1, sn = (T)0, rel;
+          if (!jacobi_rotation(gm[p * 17 + p], gm[q * 17 + q], gm[p * 17 + q], tiny, cs, sn, rel)) {
+            cs = (T)1;
+            sn = (T)0;
+          }
+          alpha[p] = cs;
+          beta[p] = -sn;
+          part[p] = q;
+          alpha[q] = cs;
+          beta[q] = sn;
+          part[q] = p;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // G <- R^T G R in one pass through g2, J <- J R
+        T gn[4], jn[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int idx = lane + 64 * e, r = idx >> 4, cx = idx & 15, pr_ = part[r];
-        gm[r * 17 + cx] = alpha[r] * g2[r * 17 + cx] + beta[r] * g2[pr_ * 17 + cx];
-        jm[r * 17 + cx] = jn[e];
+        for (int e = 0; e < 4; ++e) {
+          const int idx = lane + 64 * e, r = idx >> 4, cx = idx & 15, pc = part[cx], pr_ = part[r];
+          const T ar = alpha[r], br = beta[r], ac = alpha[cx], bc = beta[cx];
+          gn[e] = ar * (ac * gm[r * 17 + cx] + bc * gm[r * 17 + pc]) + br * (ac * gm[pr_ * 17 + cx] + bc * gm[pr_ * 17 + pc]);
+          jn[e] = ac * jm[r * 17 + cx] + bc * jm[r * 17 + pc];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int idx = lane + 64 * e, r = idx >> 4, cx = idx & 15;
+          gm[r * 17 + cx] = gn[e];
+          jm[r * 17 + cx] = jn[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
       }
-      __syncthreads();
     }
   }
-  // 4. apply J to the W and V column blocks
+  __syncthreads();
+  // 4. apply J to the W and V column blocks: wave `wave` owns the row groups it = wave, wave + 4, ...
   T jb[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) jb[ks] = jm[(4 * ks + kq) * 17 + x];
   const int64_t gx = gcol(x);
-  for (int it = 0; it < rows_pad / 16; ++it) {
+  for (int it = wave; it < nit; it += 4) {
     acc_t aw = (acc_t){0, 0, 0, 0}, av = (acc_t){0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
