@@ -337,6 +337,8 @@ struct RsvdDriver {
     dev.gemm_tn(as_rowmajor_transposed(q, l), m1, u_tall, kNone);
     // V = Qb * Uc[:, :k]
     dev.gemm_tn(as_rowmajor_transposed(qb, l), m2, v_tall, kNone);
+    // sign convention (the reference fixes none): largest-magnitude component of every v_i positive
+    dev.fix_signs(v_tall, u_tall, k);
     phase(tm.finalize_ms, pt);
     tm.total_ms += total.lap();
   }

@@ -432,6 +432,20 @@ class HipDev {
     CORRLA_HIP(hipGetLastError());
   }
 
+  // sign convention: flip (u_i, v_i) so the largest-magnitude entry of v_i is positive
+  template <class T>
+  void fix_signs(Skinny<T>& v_ref, Skinny<T>& other, int64_t k) {
+    T* sg = (T*)alloc_bytes(sizeof(T) * (size_t)k);
+    hipLaunchKernelGGL((k::column_sign_kernel<T>), dim3((unsigned)k), dim3(256), 0, stream, (const T*)v_ref.p, v_ref.ld,
+                       v_ref.rows, sg);
+    dim3 g1((unsigned)std::min<int64_t>(64, (v_ref.rows + 255) / 256), (unsigned)k);
+    hipLaunchKernelGGL((k::apply_column_sign_kernel<T>), g1, dim3(256), 0, stream, v_ref.p, v_ref.ld, v_ref.rows,
+                       (const T*)sg);
+    dim3 g2((unsigned)std::min<int64_t>(1024, (other.rows + 255) / 256), (unsigned)k);
+    hipLaunchKernelGGL((k::apply_column_sign_kernel<T>), g2, dim3(256), 0, stream, other.p, other.ld, other.rows,
+                       (const T*)sg);
+    CORRLA_HIP(hipGetLastError());
+  }
   template <class T>
   void fill_const(T* p, int64_t n, T v) {
     const int blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (n + 255) / 256));

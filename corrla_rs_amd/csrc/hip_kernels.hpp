@@ -1299,6 +1299,51 @@ __global__ void center_kernel(const T* in, int64_t rows, int64_t cols, int64_t l
   }
 }
 
+// ---- sign convention of the singular triplets ---------------------------------------------------
+// The reference leaves the signs of (u_i, v_i) to faer's SVD.  Here triplet i is normalised so that the
+// largest-magnitude component (first one on ties) of column i of the SHORT-side factor V_tall (n_t rows,
+// replicated on every rank of a sharded run) is positive.  One workgroup per column finds the sign, then
+// both factors are flipped.
+template <class T>
+__global__ void column_sign_kernel(const T* v, int64_t ld, int64_t rows, T* sign_out) {
+  const int j = blockIdx.x;
+  const T* col = v + (int64_t)j * ld;
+  T best = (T)-1;
+  int64_t best_i = 0;
+  for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) {
+    const T a = fabs(col[i]);
+    if (a > best) {
+      best = a;
+      best_i = i;
+    }
+  }
+  __shared__ T sb[256];
+  __shared__ int64_t si[256];
+  sb[threadIdx.x] = best;
+  si[threadIdx.x] = best_i;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const T ob = sb[threadIdx.x + off];
+      const int64_t oi = si[threadIdx.x + off];
+      if (ob > sb[threadIdx.x] || (ob == sb[threadIdx.x] && oi < si[threadIdx.x])) {
+        sb[threadIdx.x] = ob;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sign_out[j] = (sb[0] > (T)0 && col[si[0]] < (T)0) ? (T)-1 : (T)1;
+}
+template <class T>
+__global__ void apply_column_sign_kernel(T* m, int64_t ld, int64_t rows, const T* sign) {
+  const int j = blockIdx.y;
+  const T sg = sign[j];
+  if (sg > (T)0) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x)
+    m[(int64_t)j * ld + i] = -m[(int64_t)j * ld + i];
+}
+
 // ---- layout helpers --------------------------------------------------------------------------
 // dst[r * ldd + c] = src[r * rs + c * cs]   (repack any strided matrix to padded row-major)
 template <class T>

@@ -15,6 +15,9 @@
  *     (random_svd.rs:96-109): U m x k (leading dim ldu >= m), S k values (the k x 1 column),
  *     Vt k x n (leading dim ldvt >= k).  The caller allocates them.
  *   - l = min(rank + n_oversamples, min(m, n))   (random_svd.rs:77)
+ *   - Signs: the reference returns whatever signs faer's SVD produced.  Here every triplet (u_i, s_i, v_i)
+ *     is normalised so that the largest-magnitude component (first on ties) of the SHORT-side singular
+ *     vector (length min(m, n): v_i for tall A, u_i for fat A) is positive.
  *   - Every function returns a corrla_status; corrla_last_error() gives the thread-local
  *     message.  The reference panics instead (random_svd.rs:98-107, mat_utils.rs:170-171).
  *   - `_dev` variants take DEVICE pointers (HIP) for A and the outputs and enqueue on the

@@ -201,6 +201,24 @@ class EmuDev {
       for (int64_t c = 0; c < cols; ++c) dst[r * ldd + c] = src[r * rs + c * cs];
   }
   template <class T>
+  void fix_signs(Skinny<T>& v_ref, Skinny<T>& other, int64_t k) {
+    for (int64_t j = 0; j < k; ++j) {
+      T best = (T)-1;
+      int64_t bi = 0;
+      for (int64_t i = 0; i < v_ref.rows; ++i) {
+        const T a = std::fabs(v_ref.p[j * v_ref.ld + i]);
+        if (a > best) {
+          best = a;
+          bi = i;
+        }
+      }
+      if (best > (T)0 && v_ref.p[j * v_ref.ld + bi] < (T)0) {
+        for (int64_t i = 0; i < v_ref.rows; ++i) v_ref.p[j * v_ref.ld + i] = -v_ref.p[j * v_ref.ld + i];
+        for (int64_t i = 0; i < other.rows; ++i) other.p[j * other.ld + i] = -other.p[j * other.ld + i];
+      }
+    }
+  }
+  template <class T>
   void fill_const(T* p, int64_t n, T v) {
     for (int64_t i = 0; i < n; ++i) p[i] = v;
   }

@@ -184,3 +184,14 @@ def test_emu_pca_matches_oracle(shape, order):
     # explained variance matches the eigenvalues of the sample covariance (what PCA means)
     cov_eigs = np.sort(np.linalg.eigvalsh(np.cov(x, rowvar=False)))[::-1][:k]
     assert np.allclose((s * s / (m - 1.0)).ravel(), cov_eigs, rtol=1e-6)
+
+
+def test_sign_convention_short_side_vector_largest_component_positive():
+    rng = np.random.default_rng(12)
+    for shape in ((80, 30), (30, 80)):
+        a = rng.standard_normal(shape)
+        u, s, vt = emu_rsvd(a, 5, 2, 5, omega=rng.standard_normal((30, 10)))
+        short = vt.T if shape[0] >= shape[1] else u     # length min(m, n)
+        for i in range(5):
+            j = int(np.argmax(np.abs(short[:, i])))
+            assert short[j, i] > 0

@@ -469,3 +469,22 @@ def test_sharded_entry_point_with_world_size_1_rccl(torch):
     u0, s0, vt0 = c.rsvd(a, 16, 4, 10, omega=om)
     assert torch.equal(s0, s1) and torch.equal(u0, u1) and torch.equal(vt0, vt1)
     c.close()
+
+
+def test_sign_convention_is_stable_across_svd_paths(ctx, monkeypatch):
+    """Largest-magnitude component of the short-side singular vector is positive, so the LDS, block and host
+    SVD paths return the same signs (bitwise-different rounding, identical orientation)."""
+    g = load_golden("gauss512x256")
+    a, om = g["A"], g["omega"]
+    u0, s0, vt0 = ctx.rsvd(a, g["k"], g["q"], g["p"], omega=om)
+    for i in range(g["k"]):
+        assert vt0[i, int(np.argmax(np.abs(vt0[i, :])))] > 0
+    for mode in ("block", "host"):
+        monkeypatch.setenv("CORRLA_SVD", mode)
+        u1, s1, vt1 = ctx.rsvd(a, g["k"], g["q"], g["p"], omega=om)
+        monkeypatch.delenv("CORRLA_SVD")
+        assert np.max(np.abs(vt1 - vt0)) < 1e-8 and np.max(np.abs(u1 - u0)) < 1e-8
+    ua, sa, vta = ctx.rsvd(np.ascontiguousarray(a.T), g["k"], g["q"], g["p"], omega=om)   # fat: roles swap
+    for i in range(g["k"]):
+        assert ua[int(np.argmax(np.abs(ua[:, i]))), i] > 0
+    assert np.max(np.abs(ua - vt0.T)) < 1e-8
