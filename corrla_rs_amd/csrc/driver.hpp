@@ -157,6 +157,37 @@ struct RsvdDriver {
   int64_t orthonormalize(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough = false) {
     const int64_t l = y.cols;
     int64_t r = l;
+    if (dev.template device_chol_fits<T>(l)) {
+      // Optimistic CholeskyQR2 entirely on the device: [Gram, Cholesky + inverse, apply] x2 are enqueued
+      // back to back and the two status records are read once at the end.  Anything unusual (a failed
+      // pivot, a second Gram that is not near I) falls through to the host-controlled robust loop below,
+      // which simply continues from the current Y (every applied factor was non-singular, so the span is
+      // unchanged; a failed pass applied the identity).
+      PhaseTimer qt0;
+      const int npass = rough ? 1 : 2;
+      Skinny<T> gd0 = dev.template alloc_skinny<T>(l, l);
+      Skinny<T> md0 = dev.template alloc_skinny<T>(l, l);
+      void* st_dev = dev.alloc_bytes(128);
+      const double eps0 = (double)std::numeric_limits<T>::epsilon();
+      for (int pass = 0; pass < npass; ++pass) {
+        Skinny<T> yv = y.view_cols(l);
+        dev.gemm_nn(as_rowmajor_transposed(y, l), yv, gd0, kNone);
+        if (sharded) dev.allreduce(gd0.p, (size_t)gd0.ld * (size_t)gd0.cols_alloc);
+        dev.chol_inv(gd0, l, (T)(4.0 * eps0), md0, st_dev, pass);
+        dev.gemm_tn(as_rowmajor_transposed(y, l), md0, tmp, kNone);
+        std::swap(y.p, tmp.p);
+        ++tm.qr_passes;
+      }
+      int fail[2] = {0, 0};
+      float min_ratio[2], dev_i[2];
+      dev.read_chol_status(st_dev, npass, fail, min_ratio, dev_i);
+      phase(tm.qr_gram_ms, qt0);
+      for (int pass = 0; pass < npass; ++pass)
+        if (fail[pass] == 3) throw Error(ST_ENUMERIC, "non-finite Gram matrix in orthonormalisation");
+      if (fail[0] == 2) return 0;  // Y is the zero matrix
+      const bool ok = fail[0] == 0 && (rough || (fail[1] == 0 && dev_i[1] <= 0.25f));
+      if (ok) return l;
+    }
     const double eps = (double)std::numeric_limits<T>::epsilon();
     std::vector<double> g((size_t)l * l), mm((size_t)l * l), uu, ss, vv;
     Skinny<T> gd = dev.template alloc_skinny<T>(l, l);

@@ -87,6 +87,7 @@ class HipDev {
     split_nn_override_ = env_int("CORRLA_SPLIT_NN", 0);
     split_tn_override_ = env_int("CORRLA_SPLIT_TN", 0);
     mw_override_ = env_int("CORRLA_MW", 0);
+    no_device_chol_ = env_int("CORRLA_HOST_CHOL", 0) != 0;
     gemm_debug_flags_ = env_int("CORRLA_GEMM_DEBUG", 0);  // timing-only ablations, results are wrong
   }
   ~HipDev() {
@@ -270,6 +271,34 @@ class HipDev {
                               stream));
     if (dst_is_host) sync();
   }
+  // ---- device Cholesky + inverse (optimistic CholeskyQR2) ------------------------------------------
+  template <class T>
+  bool device_chol_fits(int64_t l) const {
+    return l <= 4096 && k::chol_inv_fits((int)l, sizeof(T)) && !no_device_chol_;
+  }
+  template <class T>
+  void chol_inv(const Skinny<T>& g, int64_t r, T piv_rel, Skinny<T>& m_out, void* st_dev, int slot) {
+    memset_zero(m_out.p, (size_t)m_out.ld * m_out.cols_alloc * sizeof(T));
+    hipLaunchKernelGGL((k::chol_inv_kernel<T>), dim3(1), dim3(k::chol_inv_threads((int)r)),
+                       k::chol_inv_lds_bytes((int)r, sizeof(T)), stream, (const T*)g.p, g.ld, (int)r, piv_rel, m_out.p,
+                       m_out.ld, (k::CholStatus*)st_dev + slot);
+    CORRLA_HIP(hipGetLastError());
+  }
+  void read_chol_status(const void* st_dev, int n, int* fail, float* min_ratio, float* dev_i) {
+    k::CholStatus h[4];
+    CORRLA_HIP(hipMemcpyAsync(h, st_dev, sizeof(k::CholStatus) * n, hipMemcpyDeviceToHost, stream));
+    sync();
+    for (int i = 0; i < n; ++i) {
+      fail[i] = h[i].fail;
+      min_ratio[i] = h[i].min_ratio;
+      dev_i[i] = h[i].dev_i;
+      if (env_int("CORRLA_DEBUG", 0) >= 2)
+        std::fprintf(stderr, "[corrla] chol_inv[%d]: fail %d min_ratio %.3g dev_i %.3g clk %lld wall %lld (%.0f MHz)\n", i,
+                     h[i].fail, h[i].min_ratio, h[i].dev_i, h[i].clk, h[i].wall,
+                     h[i].wall > 0 ? 100.0 * (double)h[i].clk / (double)h[i].wall : 0.0);
+    }
+  }
+
   // m_out (r x r) = (I + E)^(-1/2) with G = I + E given in g (overwritten by E); everything on the device
   template <class T>
   void inv_sqrt_series(Skinny<T>& g, int64_t r, Skinny<T>& m_out) {
@@ -539,6 +568,7 @@ class HipDev {
   bool events_set_[2] = {false, false};
   static constexpr size_t kPinnedBytes = (size_t)8 << 20;
   int split_nn_override_ = 0, split_tn_override_ = 0, mw_override_ = 0, gemm_debug_flags_ = 0;
+  bool no_device_chol_ = false;
 
   static void check_grid(const dim3& g) {
     if (g.y > 65535u || g.z > 65535u) throw Error(ST_EINVAL, "problem too large for the launch grid");

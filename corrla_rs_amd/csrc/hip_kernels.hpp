@@ -1265,6 +1265,200 @@ __global__ __launch_bounds__(1024) void jacobi_finish_kernel(const T* w, int64_t
   }
 }
 
+// ---- device Cholesky + triangular inverse for the Cholesky-QR passes --------------------------------
+// One workgroup: G (r x r, symmetric, column-major) -> M = R^-1 with G = R^T R (upper R), written into the
+// zero-padded skinny operand of the following apply GEMM.  G and M live in LDS.  status: fail = 0 ok / 1 =
+// pivot failure (M is then the identity: the apply becomes a no-op copy) / 2 = zero matrix / 3 = non-finite; [1] = min pivot
+// ratio d_j / g_jj, [2] = max |G - I| (both as float bits).  Lets the two passes of a CholeskyQR2 be enqueued
+// without any host round trip; the host inspects the status words once at the end.
+__device__ inline float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  return y * (2.0 - x * y);
+}
+__device__ inline float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ inline double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  return y * (1.5 - 0.5 * x * y * y);
+}
+struct CholStatus {
+  int fail;
+  float min_ratio;
+  float dev_i;
+  float gmax;
+  long long clk, wall;  // shader-clock and 100 MHz wall-clock ticks spent in the elimination loop
+};
+template <class T>
+__global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g, int64_t ldg, int r, T piv_rel, T* m,
+                                                        int64_t ldm, CholStatus* st) {
+  // Register-resident Gaussian elimination of [G | I] in one sweep of r steps, one barrier per step.
+  // Thread t owns the 4x4 tile (ti <= tk) of the upper triangle of G (v) and the same tile of W (w), where
+  // W(x, y) = L^-1(y, x) for the unit-lower factor G = L U.  Step j: the owners of row j of the reduced G
+  // publish it (rb), the owners of column j of W publish it (cb); then
+  //     G(i, k) -= rb[i] rb[k] / d_j           (i > j),
+  //     W(x, y) -= cb[x]  rb[y] / d_j          (x <= j < y).
+  // With d_j the pivots, R = D^-1/2 U and R^-1(i, c) = W(i, c) / sqrt(d_c).  Buffers are double-buffered by
+  // the parity of j so one barrier per step is enough.
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nt = (r + 3) >> 2, r4 = nt * 4;
+  T* rowbuf = (T*)smem;          // [2][r4]
+  T* colbuf = rowbuf + 2 * r4;   // [2][r4]
+  T* diag0 = colbuf + 2 * r4;    // [r4] original diagonal
+  T* dis = diag0 + r4;           // [r4] 1 / sqrt(d_j)
+  float* red = (float*)(dis + r4);  // [32]
+  const int tid = threadIdx.x, nwave = blockDim.x >> 6;
+  const int ntri = nt * (nt + 1) / 2;
+  const bool own = tid < ntri;
+  int ti = 0, tk = 0;
+  if (own) {
+    // row-major over the upper triangle of tiles (ti ascending), so that whole waves retire from the
+    // G-update once tj passes their rows
+    const int e = ntri - 1 - tid;
+    int c = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+    while (c * (c + 1) / 2 > e) --c;
+    while ((c + 1) * (c + 2) / 2 <= e) ++c;
+    ti = nt - 1 - c;
+    tk = nt - 1 - (e - c * (c + 1) / 2);
+  }
+  const int i0 = 4 * ti, k0 = 4 * tk;
+  T v[4][4], w[4][4];
+  float dv = 0.f, gm = 0.f;
+  int bad = 0;
+#pragma unroll
+  for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = i0 + aa, k = k0 + b;
+      T x = (T)0;
+      if (own && i < r && k < r) {
+        x = g[(int64_t)k * ldg + i];
+        if (!((float)fabs(x) < 3.0e38f)) bad = 1;
+        dv = fmaxf(dv, (float)fabs(x - (i == k ? (T)1 : (T)0)));
+        if (i == k) gm = fmaxf(gm, (float)x);
+      }
+      v[aa][b] = x;
+      w[aa][b] = (own && i == k && i < r) ? (T)1 : (T)0;
+    }
+  for (int idx = tid; idx < 4 * r4; idx += blockDim.x) rowbuf[idx] = (T)0;  // rowbuf and colbuf
+  if (own && ti == tk) {
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) diag0[i0 + aa] = v[aa][aa];
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    dv = fmaxf(dv, __shfl_down(dv, off, 64));
+    gm = fmaxf(gm, __shfl_down(gm, off, 64));
+  }
+  if ((tid & 63) == 0) {
+    red[tid >> 6] = dv;
+    red[16 + (tid >> 6)] = gm;
+  }
+  bad = __syncthreads_or(bad);
+  float d2 = 0.f, g2 = 0.f;
+  for (int i = 0; i < nwave; ++i) {
+    d2 = fmaxf(d2, red[i]);
+    g2 = fmaxf(g2, red[16 + i]);
+  }
+  int fl = bad ? 3 : (!(g2 > 0.f) ? 2 : 0);
+  float min_ratio = 1.f;
+  const long long clk0 = clock64(), wall0 = wall_clock64();
+  if (fl == 0) {
+    typedef T V4 __attribute__((ext_vector_type(4)));
+    for (int tj = 0; tj < nt && fl == 0; ++tj) {
+#pragma unroll
+      for (int aj = 0; aj < 4; ++aj) {  // unrolled: the published register row / column is static
+        const int j = 4 * tj + aj;
+        if (j >= r) break;
+        T* rb = rowbuf + (j & 1) * r4;
+        T* cb = colbuf + (j & 1) * r4;
+        if (own && ti == tj) *(V4*)&rb[k0] = V4{v[aj][0], v[aj][1], v[aj][2], v[aj][3]};
+        if (own && tk == tj) *(V4*)&cb[i0] = V4{w[0][aj], w[1][aj], w[2][aj], w[3][aj]};
+        __syncthreads();
+        const T d = rb[j];
+        const T g0 = diag0[j];
+        if (!(d > piv_rel * g0) || !(g0 > (T)0)) {
+          fl = 1;  // uniform: every thread reads the same d
+          break;
+        }
+        if (tid < 64) {
+          min_ratio = fminf(min_ratio, (float)d * fast_rcp((float)g0));
+          if (tid == 0) {
+            T rs = fast_rsqrt(d);
+            rs = rs * ((T)1.5 - (T)0.5 * d * rs * rs);
+            dis[j] = rs;
+          }
+        }
+        if (own && tk >= tj) {  // tiles left of the pivot column are finished
+          T rinv = fast_rcp(d);
+          rinv = rinv * ((T)2 - d * rinv);
+          const V4 rk4 = *(const V4*)&rb[k0];
+          T rk[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rk[q] = rk4[q] * rinv;
+          if (ti >= tj) {
+            const V4 ri4 = *(const V4*)&rb[i0];
+            T ri[4] = {ri4[0], ri4[1], ri4[2], ri4[3]};
+            if (ti == tj) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) ri[q] = (q > aj) ? ri[q] : (T)0;  // rows at or above the pivot stay
+            }
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+              for (int b = 0; b < 4; ++b) v[aa][b] -= ri[aa] * rk[b];
+          }
+          if (ti <= tj) {
+            const V4 ci4 = *(const V4*)&cb[i0];
+            T ci[4] = {ci4[0], ci4[1], ci4[2], ci4[3]};
+            if (ti == tj) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) ci[q] = (q <= aj) ? ci[q] : (T)0;  // W(x, y): x <= j
+            }
+            if (tk == tj) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) rk[q] = (q > aj) ? rk[q] : (T)0;  // W(x, y): y > j
+            }
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+              for (int b = 0; b < 4; ++b) w[aa][b] -= ci[aa] * rk[b];
+          }
+        }
+      }
+    }
+  }
+  const long long clk1 = clock64(), wall1 = wall_clock64();
+  __syncthreads();
+  if (own) {
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = i0 + aa, k = k0 + b;
+        if (i <= k && k < r)
+          m[(int64_t)k * ldm + i] = (fl == 0) ? w[aa][b] * dis[k] : ((i == k && fl == 1) ? (T)1 : (T)0);
+      }
+  }
+  if (tid == 0) {
+    st->fail = fl;
+    st->min_ratio = min_ratio;
+    st->dev_i = d2;
+    st->gmax = g2;
+    st->clk = clk1 - clk0;
+    st->wall = wall1 - wall0;
+  }
+}
+__host__ __device__ inline int chol_inv_threads(int r) {
+  const int nt = (r + 3) / 4;
+  return ((nt * (nt + 1) / 2 + 63) / 64) * 64;
+}
+__host__ __device__ inline size_t chol_inv_lds_bytes(int r, size_t esz) {
+  return (size_t)6 * (((size_t)r + 3) / 4 * 4) * esz + 32 * sizeof(float) + 64;
+}
+__host__ __device__ inline bool chol_inv_fits(int r, size_t esz) {
+  (void)esz;
+  return r >= 1 && chol_inv_threads(r) <= 1024;  // r <= 176
+}
+
 // ---- (I + E)^(-1/2) by its Taylor series, for the polishing pass of the Cholesky-QR ---------------
 // g (r x r, column-major, ld) holds G = I + E on entry, E on exit
 template <class T>

@@ -163,6 +163,62 @@ class EmuDev {
   }
   template <class T>
   void store_values(const T* src, int64_t n, T* dst, bool) { std::memcpy(dst, src, sizeof(T) * n); }
+  // same status semantics as k::chol_inv_kernel (0 ok, 1 pivot failure -> identity, 2 zero, 3 non-finite)
+  struct EmuCholStatus {
+    int fail;
+    float min_ratio, dev_i, gmax;
+  };
+  template <class T>
+  bool device_chol_fits(int64_t l) const {
+    return l <= 176 && !std::getenv("CORRLA_EMU_NO_DEVICE_CHOL");
+  }
+  template <class T>
+  void chol_inv(const Skinny<T>& g, int64_t r, T piv_rel, Skinny<T>& m_out, void* st_dev, int slot) {
+    EmuCholStatus* st = (EmuCholStatus*)st_dev + slot;
+    std::vector<double> a((size_t)r * r);
+    double dv = 0.0, gm = 0.0;
+    bool finite = true;
+    for (int64_t j = 0; j < r; ++j)
+      for (int64_t i = 0; i < r; ++i) {
+        const double v = (double)g.p[j * g.ld + i];
+        a[j * r + i] = v;
+        finite = finite && std::isfinite(v);
+        dv = std::max(dv, std::fabs(v - (i == j ? 1.0 : 0.0)));
+        if (i == j) gm = std::max(gm, v);
+      }
+    std::memset(m_out.p, 0, (size_t)m_out.ld * m_out.cols_alloc * sizeof(T));
+    st->dev_i = (float)dv;
+    st->gmax = (float)gm;
+    st->min_ratio = 1.f;
+    if (!finite) {
+      st->fail = 3;
+      return;
+    }
+    if (!(gm > 0.0)) {
+      st->fail = 2;
+      return;
+    }
+    double mr = 0.0;
+    // the device kernel factorizes in T precision: round G through T first
+    if (!small::chol_upper((int)r, a.data(), (int)r, (double)piv_rel, &mr)) {
+      st->fail = 1;
+      for (int64_t i = 0; i < r; ++i) m_out.p[i * m_out.ld + i] = (T)1;
+      return;
+    }
+    small::triu_inverse((int)r, a.data(), (int)r);
+    for (int64_t j = 0; j < r; ++j)
+      for (int64_t i = 0; i <= j; ++i) m_out.p[j * m_out.ld + i] = (T)a[j * r + i];
+    st->fail = 0;
+    st->min_ratio = (float)mr;
+  }
+  void read_chol_status(const void* st_dev, int n, int* fail, float* min_ratio, float* dev_i) {
+    const EmuCholStatus* st = (const EmuCholStatus*)st_dev;
+    for (int i = 0; i < n; ++i) {
+      fail[i] = st[i].fail;
+      min_ratio[i] = st[i].min_ratio;
+      dev_i[i] = st[i].dev_i;
+    }
+  }
   template <class T>
   void inv_sqrt_series(Skinny<T>& g, int64_t r, Skinny<T>& m_out) {
     std::vector<double> e((size_t)r * r), e2((size_t)r * r, 0.0), e3((size_t)r * r, 0.0);
