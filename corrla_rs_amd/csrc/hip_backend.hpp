@@ -76,6 +76,8 @@ class HipDev {
     set_lds_attrs<double>();
     set_jacobi_attrs<float>();
     set_jacobi_attrs<double>();
+    set_ring_attrs<float, 20>();
+    set_ring_attrs<double, 18>();
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<float>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<double>,
@@ -322,6 +324,14 @@ class HipDev {
     CORRLA_HIP(hipGetLastError());
   }
 
+  template <class T, int BIG_E>
+  void set_ring_attrs() {
+    const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, 8>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, 12>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, BIG_E>, attr, 160 * 1024));
+  }
+
   // SVD of the l x l core (random_svd.rs:89).  Default: single-workgroup LDS-resident Jacobi when W fits
   // in LDS, block Jacobi over many waves otherwise (any l up to 1024).  CORRLA_SVD=block / host force the
   // block kernel / the f64 host Jacobi.
@@ -393,6 +403,29 @@ class HipDev {
     const T tol_early = (T)std::sqrt(eps);  // quadratic convergence: a sweep that starts below this ends below tol
     const bool v_lds = lds2 <= kLdsMax;
     const size_t lds = v_lds ? lds2 : lds1;
+    // ring kernel: columns resident in registers (l <= 144)
+    if (l >= 2 && l <= 144 && !env_int("CORRLA_JACOBI_NORING", 0)) {
+      const int np = (int)((l + 1) / 2);
+      const dim3 block((unsigned)round_up(np * 8, 64));
+      const int max_sw = env_int("CORRLA_JACOBI_SWEEPS", 40);
+#define CORRLA_RING(EE)                                                                                              \
+  hipLaunchKernelGGL((k::jacobi_ring_kernel<T, EE>), dim3(1), block, k::jacobi_ring_lds_bytes((int)l, EE, sizeof(T)), \
+                     stream, (const T*)c.p, c.ld, (int)l, m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, tol_early,     \
+                     max_sw, info)
+      constexpr int kBigE = sizeof(T) == 4 ? 20 : 18;
+      if (l <= 64) CORRLA_RING(8);
+      else if (l <= 96) CORRLA_RING(12);
+      else CORRLA_RING(kBigE);
+#undef CORRLA_RING
+      CORRLA_HIP(hipGetLastError());
+      if (env_int("CORRLA_DEBUG", 0)) {
+        int h[4] = {0, 0, 0, 0};
+        CORRLA_HIP(hipMemcpyAsync(h, info, sizeof(int), hipMemcpyDeviceToHost, stream));
+        sync();
+        std::fprintf(stderr, "[corrla] jacobi_svd (ring) l=%d sweeps=%d\n", (int)l, h[0]);
+      }
+      return;
+    }
     // role-split kernel: W updates and V updates on different waves (needs both images in LDS, <= 72 pairs,
     // <= 36 sixteen-byte chunks per column)
     const size_t lds_split = k::jacobi_split_lds_bytes((int)l, sizeof(T));

@@ -1042,6 +1042,230 @@ __host__ __device__ inline size_t jacobi_lds_bytes(int l, size_t esz, bool v_in_
   return (size_t)l * jacobi_pitch(l, vw) * esz * (v_in_lds ? 2 : 1) + (size_t)(l + 2) * esz +
          (size_t)(l + 2) * sizeof(int) + 64;
 }
+// ---- ring Jacobi: columns resident in registers --------------------------------------------------
+// Same one-sided Jacobi, but the two columns a processor (8 lanes) works on stay in REGISTERS (W and V,
+// lane g owning the 16-byte row chunks g, g + 8, ...), and the pairs follow the odd-even transposition
+// ordering: processor i holds the columns at line positions (2i, 2i + 1); after every rotation the two
+// columns swap positions, and the window of every processor slides by one position back and forth, so
+// only ONE column per processor crosses LDS per round (half the traffic of the LDS-resident kernels, no
+// address arithmetic or predication in the loop).  n rounds make every pair of columns meet exactly once.
+// Even round: rotate (P, Q), send Q to processor i - 1, receive Q from i + 1.  Odd round: rotate (P, Q),
+// send P to i + 1, receive P from i - 1; the last processor then holds (position n - 1, wrapped position 0),
+// which are not a pair of the line ordering: it applies (cs, sn) = (0, 1), i.e. P <- -Q, Q <- P, a swap that
+// flips the sign of one singular-vector pair.  V lags W by half a round so its update overlaps the exchange.
+__device__ __forceinline__ float ring_sum8(float x) { return group_sum<8>(x); }
+__device__ __forceinline__ double ring_sum8(double x) {
+  auto dpp = [](double v, auto ctrl) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, decltype(ctrl)::value, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, decltype(ctrl)::value, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{});
+  x += dpp(x, std::integral_constant<int, 0x4E>{});
+  x += dpp(x, std::integral_constant<int, 0x141>{});
+  return x;
+}
+constexpr int kRingMaxThreads = 576;  // 72 processors x 8 lanes
+template <class T, int E>
+__global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_kernel(const T* __restrict__ c, int64_t ldc, int l, T* m1,
+                                                                      int64_t ld1, T* m2, int64_t ld2, T* s_out, int k,
+                                                                      T tol, T tol_early, int max_sweeps, int* info) {
+  typedef typename MT<T>::vec_t vec_t;
+  constexpr int VW = MT<T>::VEC;
+  static_assert(E % VW == 0, "whole 16-byte chunks per lane");
+  constexpr int NC = E / VW;
+  constexpr int RS = 8 * E;  // padded column length
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n2 = (l + 1) & ~1, np = n2 >> 1;
+  T* xw = (T*)smem;                  // [np][RS] W column in flight
+  T* xv = xw + (size_t)np * RS;      // [np][RS] V column in flight
+  T* sigma = xv + (size_t)np * RS;   // [n2]
+  int* rank = (int*)(sigma + n2);    // [n2]
+  int* flag = rank + n2;             // [4]
+  const int tid = threadIdx.x, proc = tid >> 3, g = tid & 7;
+  const bool act = proc < np;
+  const bool last = proc == np - 1;
+  vec_t pw[NC], qw[NC], pv[NC], qv[NC];
+  {
+    const int colp = 2 * proc, colq = 2 * proc + 1;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+      for (int z = 0; z < VW; ++z) {
+        const int row = (cc * 8 + g) * VW + z;
+        const bool ok = act && row < l;
+        pw[cc][z] = (ok && colp < l) ? c[(int64_t)colp * ldc + row] : (T)0;
+        qw[cc][z] = (ok && colq < l) ? c[(int64_t)colq * ldc + row] : (T)0;
+        pv[cc][z] = (ok && row == colp) ? (T)1 : (T)0;
+        qv[cc][z] = (ok && row == colq) ? (T)1 : (T)0;
+      }
+  }
+  const int my_off = proc * RS + g * VW;
+  const int up_off = (proc + 1 >= np ? 0 : proc + 1) * RS + g * VW;
+  const int dn_off = (proc == 0 ? np - 1 : proc - 1) * RS + g * VW;
+  auto store = [&](T* buf, const vec_t (&x)[NC]) {
+    if (act) {
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) *(vec_t*)(buf + my_off + cc * 8 * VW) = x[cc];
+    }
+  };
+  auto load = [&](const T* buf, int off, vec_t (&x)[NC]) {
+    if (act) {
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) x[cc] = *(const vec_t*)(buf + off + cc * 8 * VW);
+    }
+  };
+  // rotation of the W pair in registers; forced: the wrap-around pseudo pair of the last processor
+  auto rotate_w = [&](bool forced, T& cs, T& sn) {
+    vec_t va, vb, vg;
+#pragma unroll
+    for (int z = 0; z < VW; ++z) va[z] = vb[z] = vg[z] = (T)0;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      va += pw[cc] * pw[cc];
+      vb += qw[cc] * qw[cc];
+      vg += pw[cc] * qw[cc];
+    }
+    T a = va[0], b = vb[0], gg = vg[0];
+#pragma unroll
+    for (int z = 1; z < VW; ++z) {
+      a += va[z];
+      b += vb[z];
+      gg += vg[z];
+    }
+    a = ring_sum8(a);
+    b = ring_sum8(b);
+    gg = ring_sum8(gg);
+    T rel = (T)0;
+    cs = (T)1;
+    sn = (T)0;
+    const bool rot = !forced && jacobi_rotation(a, b, gg, tol, cs, sn, rel);
+    if (rot) {
+      if (g == 0) {
+        flag[0] = 1;
+        if (rel > tol_early) flag[1] = 1;
+      }
+    } else {
+      cs = forced ? (T)0 : (T)1;
+      sn = forced ? (T)1 : (T)0;
+    }
+    if (sn != (T)0) {
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        const vec_t x = pw[cc], y = qw[cc];
+        pw[cc] = cs * x - sn * y;
+        qw[cc] = sn * x + cs * y;
+      }
+    }
+  };
+  auto apply_v = [&](T cs, T sn) {
+    if (sn != (T)0) {
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        const vec_t x = pv[cc], y = qv[cc];
+        pv[cc] = cs * x - sn * y;
+        qv[cc] = sn * x + cs * y;
+      }
+    }
+  };
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid < 2) flag[tid] = 0;
+    __syncthreads();
+    for (int r2 = 0; r2 < np; ++r2) {
+      T cs, sn;
+      // even round
+      rotate_w(false, cs, sn);
+      store(xw, qw);
+      __syncthreads();
+      apply_v(cs, sn);
+      store(xv, qv);
+      load(xw, up_off, qw);
+      __syncthreads();
+      load(xv, up_off, qv);
+      // odd round
+      rotate_w(last, cs, sn);
+      store(xw, pw);
+      __syncthreads();
+      apply_v(cs, sn);
+      store(xv, pv);
+      load(xw, dn_off, pw);
+      __syncthreads();
+      load(xv, dn_off, pv);
+    }
+    __syncthreads();
+    const int rotated = flag[0], big = flag[1];
+    __syncthreads();
+    if (!rotated || !big) {
+      if (rotated) ++sweep;
+      break;
+    }
+  }
+  // singular values; the zero padding column of an odd l (its V column is zero too) sorts last
+  {
+    T a = 0, b = 0, va = 0, vb = 0;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+      for (int z = 0; z < VW; ++z) {
+        a += pw[cc][z] * pw[cc][z];
+        b += qw[cc][z] * qw[cc][z];
+        va += pv[cc][z] * pv[cc][z];
+        vb += qv[cc][z] * qv[cc][z];
+      }
+    a = ring_sum8(a);
+    b = ring_sum8(b);
+    va = ring_sum8(va);
+    vb = ring_sum8(vb);
+    if (act && g == 0) {
+      sigma[2 * proc] = va > (T)0 ? sqrt(a) : (T)-1;
+      sigma[2 * proc + 1] = vb > (T)0 ? sqrt(b) : (T)-1;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < n2; j += blockDim.x) {
+    const T sj = sigma[j];
+    int r = 0;
+    for (int i = 0; i < n2; ++i) {
+      const T si = sigma[i];
+      r += (si > sj || (si == sj && i < j)) ? 1 : 0;
+    }
+    rank[j] = r;
+  }
+  __syncthreads();
+  if (act) {
+    const int rp = rank[2 * proc], rq = rank[2 * proc + 1];
+    const T sp = sigma[2 * proc], sq = sigma[2 * proc + 1];
+    const T ip = sp > (T)0 ? (T)1 / sp : (T)0, iq = sq > (T)0 ? (T)1 / sq : (T)0;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+      for (int z = 0; z < VW; ++z) {
+        const int row = (cc * 8 + g) * VW + z;
+        if (row < l) {
+          if (rp < k) {
+            m2[(int64_t)rp * ld2 + row] = pw[cc][z] * ip;
+            m1[(int64_t)rp * ld1 + row] = pv[cc][z];
+          }
+          if (rq < k) {
+            m2[(int64_t)rq * ld2 + row] = qw[cc][z] * iq;
+            m1[(int64_t)rq * ld1 + row] = qv[cc][z];
+          }
+        }
+      }
+    if (g == 0) {
+      if (rp < k) s_out[rp] = sp > (T)0 ? sp : (T)0;
+      if (rq < k) s_out[rq] = sq > (T)0 ? sq : (T)0;
+    }
+  }
+  if (tid == 0) info[0] = sweep;
+}
+__host__ __device__ inline size_t jacobi_ring_lds_bytes(int l, int e, size_t esz) {
+  const int n2 = (l + 1) & ~1;
+  return (size_t)2 * (n2 / 2) * 8 * e * esz + (size_t)n2 * (esz + sizeof(int)) + 64;
+}
+
 constexpr int kJacobiMaxL = 256;  // 8-lane groups x 8 chunks x 4 elements
 
 // ---- block Jacobi SVD of the l x l core for any l (random_svd.rs:89) -----------------------------
