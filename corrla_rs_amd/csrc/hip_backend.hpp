@@ -280,7 +280,7 @@ class HipDev {
   }
   template <class T>
   void chol_inv(const Skinny<T>& g, int64_t r, T piv_rel, Skinny<T>& m_out, void* st_dev, int slot) {
-    memset_zero(m_out.p, (size_t)m_out.ld * m_out.cols_alloc * sizeof(T));
+    // m_out comes zero-filled from alloc_skinny and only its upper triangle is ever written
     hipLaunchKernelGGL((k::chol_inv_kernel<T>), dim3(1), dim3(k::chol_inv_threads((int)r)),
                        k::chol_inv_lds_bytes((int)r, sizeof(T)), stream, (const T*)g.p, g.ld, (int)r, piv_rel, m_out.p,
                        m_out.ld, (k::CholStatus*)st_dev + slot);
@@ -329,6 +329,7 @@ class HipDev {
     const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, 8>, attr, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, 12>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, 16>, attr, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, BIG_E>, attr, 160 * 1024));
   }
 
@@ -415,6 +416,7 @@ class HipDev {
       constexpr int kBigE = sizeof(T) == 4 ? 20 : 18;
       if (l <= 64) CORRLA_RING(8);
       else if (l <= 96) CORRLA_RING(12);
+      else if (l <= 128) CORRLA_RING(16);
       else CORRLA_RING(kBigE);
 #undef CORRLA_RING
       CORRLA_HIP(hipGetLastError());
@@ -733,7 +735,13 @@ class HipDev {
       default: throw Error(ST_EINVAL, "internal: bad column blocking");
     }
     CORRLA_HIP(hipGetLastError());
-    if (nsplit > 1) {
+    if (nsplit >= 8) {
+      dim3 rg((unsigned)((outer_n + 63) / 64), (unsigned)cb.cols_alloc);
+      check_grid(rg);
+      hipLaunchKernelGGL((k::slab_reduce_deep_kernel<T>), rg, dim3(256), 0, stream, (const T*)a.slab, a.slab_stride,
+                         nsplit, out.p, out.ld, outer_n, cb.cols_alloc, scale_dev);
+      CORRLA_HIP(hipGetLastError());
+    } else if (nsplit > 1) {
       dim3 rg((unsigned)((outer_n + 255) / 256), (unsigned)cb.cols_alloc);
       check_grid(rg);
       hipLaunchKernelGGL((k::slab_reduce_kernel<T>), rg, dim3(256), 0, stream, (const T*)a.slab, a.slab_stride, nsplit,

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
     store_tile<T, NT>(g, acc[mw], n0 + 16 * MW * wave + 16 * mw, g.r_cols, col0, lane);
 }
 
-// out[col][i] = scale * sum_z slab[z][col][i], i < limit, col < ncols; fixed z order (deterministic)
+// out[col][i] = scale * sum_z slab[z][col][i], i < limit, col < ncols; fixed summation tree (deterministic)
 template <class T>
 __global__ void slab_reduce_kernel(const T* slab, int64_t slab_stride, int nsplit, T* out, int64_t ld, int64_t limit,
                                    int64_t ncols, const T* scale) {
@@ -548,6 +548,36 @@ __global__ void slab_reduce_kernel(const T* slab, int64_t slab_stride, int nspli
   for (int z = 0; z < nsplit; ++z) s += slab[(int64_t)z * slab_stride + off];
   if (scale) s *= *scale;
   out[off] = s;
+}
+// many slabs, small output (the Gram matrices): 64 outputs x 4 slab groups per block, four loads in flight each
+template <class T>
+__global__ __launch_bounds__(256) void slab_reduce_deep_kernel(const T* slab, int64_t slab_stride, int nsplit, T* out,
+                                                               int64_t ld, int64_t limit, int64_t ncols, const T* scale) {
+  __shared__ T part[4][64];
+  const int li = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + li;
+  const int64_t col = blockIdx.y;
+  const int per = (nsplit + 3) / 4;
+  const int z0 = zg * per, z1 = min(nsplit, z0 + per);
+  T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  if (i < limit && col < ncols) {
+    const T* src = slab + col * ld + i;
+    int z = z0;
+    for (; z + 3 < z1; z += 4) {
+      s0 += src[(int64_t)z * slab_stride];
+      s1 += src[(int64_t)(z + 1) * slab_stride];
+      s2 += src[(int64_t)(z + 2) * slab_stride];
+      s3 += src[(int64_t)(z + 3) * slab_stride];
+    }
+    for (; z < z1; ++z) s0 += src[(int64_t)z * slab_stride];
+  }
+  part[zg][li] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (zg == 0 && i < limit && col < ncols) {
+    T s = (part[0][li] + part[1][li]) + (part[2][li] + part[3][li]);
+    if (scale) s *= *scale;
+    out[col * ld + i] = s;
+  }
 }
 
 // ---- Frobenius norm pieces (random_svd.rs:53-55) ----------------------------------------------
@@ -677,28 +707,38 @@ __device__ __forceinline__ double group_sum(double x) {
 // Jacobi rotation (cos, sin) that annihilates the off-diagonal g of [[a, g], [g, b]]; `rel` receives
 // |g| / sqrt(a b).  f32 uses the single-instruction reciprocal / rsqrt (~1 ulp; the Jacobi kernels are
 // VALU-issue bound and the IEEE sqrt/div sequences were ~1/4 of their instruction stream); f64 stays IEEE.
-__device__ __forceinline__ bool jacobi_rotation(float a, float b, float g, float tol, float& cs, float& sn, float& rel) {
+__device__ __forceinline__ bool jacobi_rotation(float a, float b, float g, float tol, float& cs, float& sn, float& rel,
+                                                float& t) {
   const float ab2 = a * b;
   const float rs = ab2 > 0.f ? __builtin_amdgcn_rsqf(ab2) : 0.f;
   rel = fabsf(g) * rs;
   if (!(rel > tol)) return false;
   const float zeta = (b - a) * 0.5f * __builtin_amdgcn_rcpf(g);
   const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta);
-  const float t = copysignf(__builtin_amdgcn_rcpf(den), zeta);
+  t = copysignf(__builtin_amdgcn_rcpf(den), zeta);
   cs = __builtin_amdgcn_rsqf(1.f + t * t);
+  sn = cs * t;
+  return true;
+}
+__device__ __forceinline__ bool jacobi_rotation(float a, float b, float g, float tol, float& cs, float& sn, float& rel) {
+  float t;
+  return jacobi_rotation(a, b, g, tol, cs, sn, rel, t);
+}
+__device__ __forceinline__ bool jacobi_rotation(double a, double b, double g, double tol, double& cs, double& sn,
+                                                double& rel, double& t) {
+  const double ab = sqrt(a * b);
+  rel = ab > 0.0 ? fabs(g) / ab : 0.0;
+  if (!(rel > tol)) return false;
+  const double zeta = (b - a) / (2.0 * g);
+  t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  cs = 1.0 / sqrt(1.0 + t * t);
   sn = cs * t;
   return true;
 }
 __device__ __forceinline__ bool jacobi_rotation(double a, double b, double g, double tol, double& cs, double& sn,
                                                 double& rel) {
-  const double ab = sqrt(a * b);
-  rel = ab > 0.0 ? fabs(g) / ab : 0.0;
-  if (!(rel > tol)) return false;
-  const double zeta = (b - a) / (2.0 * g);
-  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-  cs = 1.0 / sqrt(1.0 + t * t);
-  sn = cs * t;
-  return true;
+  double t;
+  return jacobi_rotation(a, b, g, tol, cs, sn, rel, t);
 }
 // pair (p < q) of slot `pr` in round `step` of the round-robin tournament on n players (no integer division)
 __device__ __forceinline__ void tournament_pair(int n, int step, int pr, int& p, int& q) {
@@ -1081,7 +1121,8 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_kernel(const T* _
   T* xw = (T*)smem;                  // [np][RS] W column in flight
   T* xv = xw + (size_t)np * RS;      // [np][RS] V column in flight
   T* sigma = xv + (size_t)np * RS;   // [n2]
-  int* rank = (int*)(sigma + n2);    // [n2]
+  T* xn = sigma + n2;                // [np] squared norm of the W column in flight
+  int* rank = (int*)(xn + np);       // [n2]
   int* flag = rank + n2;             // [4]
   const int tid = threadIdx.x, proc = tid >> 3, g = tid & 7;
   const bool act = proc < np;
@@ -1116,39 +1157,58 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_kernel(const T* _
       for (int cc = 0; cc < NC; ++cc) x[cc] = *(const vec_t*)(buf + off + cc * 8 * VW);
     }
   };
-  // rotation of the W pair in registers; forced: the wrap-around pseudo pair of the last processor
-  auto rotate_w = [&](bool forced, T& cs, T& sn) {
-    vec_t va, vb, vg;
+  // squared norms of the two resident W columns: recomputed from the registers at the start of every sweep,
+  // updated analytically by each rotation in between (a' = a - t g, b' = b + t g), and travelling with their
+  // column through xn, so a round needs ONE dot product instead of three
+  T na = (T)0, nb = (T)0;
+  auto recompute_norms = [&]() {
+    vec_t va, vb;
 #pragma unroll
-    for (int z = 0; z < VW; ++z) va[z] = vb[z] = vg[z] = (T)0;
+    for (int z = 0; z < VW; ++z) va[z] = vb[z] = (T)0;
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
       va += pw[cc] * pw[cc];
       vb += qw[cc] * qw[cc];
-      vg += pw[cc] * qw[cc];
     }
-    T a = va[0], b = vb[0], gg = vg[0];
+    T a = va[0], b = vb[0];
 #pragma unroll
     for (int z = 1; z < VW; ++z) {
       a += va[z];
       b += vb[z];
-      gg += vg[z];
     }
-    a = ring_sum8(a);
-    b = ring_sum8(b);
+    na = ring_sum8(a);
+    nb = ring_sum8(b);
+  };
+  // rotation of the W pair in registers; forced: the wrap-around pseudo pair of the last processor
+  auto rotate_w = [&](bool forced, T& cs, T& sn) {
+    vec_t vg;
+#pragma unroll
+    for (int z = 0; z < VW; ++z) vg[z] = (T)0;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) vg += pw[cc] * qw[cc];
+    T gg = vg[0];
+#pragma unroll
+    for (int z = 1; z < VW; ++z) gg += vg[z];
     gg = ring_sum8(gg);
-    T rel = (T)0;
+    T rel = (T)0, t = (T)0;
     cs = (T)1;
     sn = (T)0;
-    const bool rot = !forced && jacobi_rotation(a, b, gg, tol, cs, sn, rel);
+    const bool rot = !forced && jacobi_rotation(na, nb, gg, tol, cs, sn, rel, t);
     if (rot) {
       if (g == 0) {
         flag[0] = 1;
         if (rel > tol_early) flag[1] = 1;
       }
+      na -= t * gg;
+      nb += t * gg;
     } else {
       cs = forced ? (T)0 : (T)1;
       sn = forced ? (T)1 : (T)0;
+      if (forced) {
+        const T tmp = na;
+        na = nb;
+        nb = tmp;
+      }
     }
     if (sn != (T)0) {
 #pragma unroll
@@ -1169,28 +1229,34 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_kernel(const T* _
       }
     }
   };
+  const int up_proc = proc + 1 >= np ? 0 : proc + 1, dn_proc = proc == 0 ? np - 1 : proc - 1;
   int sweep = 0;
   for (; sweep < max_sweeps; ++sweep) {
     if (tid < 2) flag[tid] = 0;
+    recompute_norms();
     __syncthreads();
     for (int r2 = 0; r2 < np; ++r2) {
       T cs, sn;
       // even round
       rotate_w(false, cs, sn);
       store(xw, qw);
+      if (act && g == 0) xn[proc] = nb;
       __syncthreads();
       apply_v(cs, sn);
       store(xv, qv);
       load(xw, up_off, qw);
+      if (act) nb = xn[up_proc];
       __syncthreads();
       load(xv, up_off, qv);
       // odd round
       rotate_w(last, cs, sn);
       store(xw, pw);
+      if (act && g == 0) xn[proc] = na;
       __syncthreads();
       apply_v(cs, sn);
       store(xv, pv);
       load(xw, dn_off, pw);
+      if (act) na = xn[dn_proc];
       __syncthreads();
       load(xv, dn_off, pv);
     }
@@ -1263,7 +1329,7 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_kernel(const T* _
 }
 __host__ __device__ inline size_t jacobi_ring_lds_bytes(int l, int e, size_t esz) {
   const int n2 = (l + 1) & ~1;
-  return (size_t)2 * (n2 / 2) * 8 * e * esz + (size_t)n2 * (esz + sizeof(int)) + 64;
+  return (size_t)2 * (n2 / 2) * 8 * e * esz + (size_t)n2 * (esz + sizeof(int)) + (size_t)(n2 / 2) * esz + 64;
 }
 
 constexpr int kJacobiMaxL = 256;  // 8-lane groups x 8 chunks x 4 elements
