@@ -331,6 +331,10 @@ class HipDev {
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, 12>, attr, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, 16>, attr, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, BIG_E>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 8>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 12>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, BIG_E>, attr, 160 * 1024));
   }
 
   // SVD of the l x l core (random_svd.rs:89).  Default: single-workgroup LDS-resident Jacobi when W fits
@@ -409,10 +413,25 @@ class HipDev {
       const int np = (int)((l + 1) / 2);
       const dim3 block((unsigned)round_up(np * 8, 64));
       const int max_sw = env_int("CORRLA_JACOBI_SWEEPS", 40);
-#define CORRLA_RING(EE)                                                                                              \
-  hipLaunchKernelGGL((k::jacobi_ring_kernel<T, EE>), dim3(1), block, k::jacobi_ring_lds_bytes((int)l, EE, sizeof(T)), \
-                     stream, (const T*)c.p, c.ld, (int)l, m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, tol_early,     \
-                     max_sw, info)
+      const bool replay = !env_int("CORRLA_JACOBI_NOREPLAY", 0);
+      const int n2 = 2 * np;
+      k::RotEntry<T>* rot = nullptr;
+      int* rank_g = nullptr;
+      if (replay) {
+        rot = (k::RotEntry<T>*)alloc_bytes((size_t)max_sw * n2 * k::kRingProcPad * sizeof(k::RotEntry<T>));
+        rank_g = (int*)alloc_bytes(sizeof(int) * (size_t)n2);
+      }
+#define CORRLA_RING(EE)                                                                                                  \
+  do {                                                                                                                   \
+    if (replay)                                                                                                          \
+      hipLaunchKernelGGL((k::jacobi_ring_w_kernel<T, EE>), dim3(1), block, k::jacobi_ring_w_lds_bytes((int)l, EE, sizeof(T)), \
+                         stream, (const T*)c.p, c.ld, (int)l, m2.p, m2.ld, s_dev, (int)k, tol, tol_early, max_sw, rot,     \
+                         rank_g, info);                                                                                  \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((k::jacobi_ring_kernel<T, EE>), dim3(1), block, k::jacobi_ring_lds_bytes((int)l, EE, sizeof(T)), \
+                         stream, (const T*)c.p, c.ld, (int)l, m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, tol_early,    \
+                         max_sw, info);                                                                                  \
+  } while (0)
       constexpr int kBigE = sizeof(T) == 4 ? 20 : 18;
       if (l <= 64) CORRLA_RING(8);
       else if (l <= 96) CORRLA_RING(12);
@@ -420,6 +439,12 @@ class HipDev {
       else CORRLA_RING(kBigE);
 #undef CORRLA_RING
       CORRLA_HIP(hipGetLastError());
+      if (replay) {
+        hipLaunchKernelGGL((k::jacobi_replay_v_kernel<T>), dim3((unsigned)((l + 256 / k::kReplayLanes - 1) / (256 / k::kReplayLanes))), dim3(256), 0,
+                           stream,
+                           (const k::RotEntry<T>*)rot, (const int*)info, (const int*)rank_g, (int)l, (int)k, m1.p, m1.ld);
+        CORRLA_HIP(hipGetLastError());
+      }
       if (env_int("CORRLA_DEBUG", 0)) {
         int h[4] = {0, 0, 0, 0};
         CORRLA_HIP(hipMemcpyAsync(h, info, sizeof(int), hipMemcpyDeviceToHost, stream));

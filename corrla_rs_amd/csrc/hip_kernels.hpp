@@ -1327,6 +1327,346 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_kernel(const T* _
   }
   if (tid == 0) info[0] = sweep;
 }
+// ---- ring Jacobi, W only + replay of the rotation stream onto V ------------------------------------
+// The ring kernel above is VALU-issue bound and ~45 % of its instructions accumulate V.  The rows of V are
+// independent and need nothing but the (cs, sn) of every round, so: jacobi_ring_w_kernel keeps only W in
+// registers, records every round's rotations in a global stream (rot[round][processor] = (cs, sn), identity for
+// skipped pairs) and -- with the V buffer gone from LDS -- double-buffers the W exchange: ONE barrier per
+// round.  jacobi_replay_v_kernel then applies the recorded stream to V = I with 8 lanes per ROW of V (18
+// positions per lane in registers), 32 rows per workgroup, on as many CUs as there are row groups.  Line
+// positions after S sweeps are known in closed form (always-swap odd-even transposition reverses the order
+// every sweep), so the W kernel only has to publish rank[position] for the replay to scatter V_c[:, :k].
+constexpr int kRingProcPad = 72;  // processors per stream row (padded)
+template <class T>
+struct RotEntry {
+  T cs, sn;
+};
+template <class T, int E>
+__global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T* __restrict__ c, int64_t ldc, int l, T* m2,
+                                                                        int64_t ld2, T* s_out, int k, T tol, T tol_early,
+                                                                        int max_sweeps, RotEntry<T>* rot, int* rank_g,
+                                                                        int* info) {
+  typedef typename MT<T>::vec_t vec_t;
+  constexpr int VW = MT<T>::VEC;
+  static_assert(E % VW == 0, "whole 16-byte chunks per lane");
+  constexpr int NC = E / VW;
+  constexpr int RS = 8 * E;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n2 = (l + 1) & ~1, np = n2 >> 1;
+  T* xw = (T*)smem;                      // [2][np][RS] W column in flight (double-buffered)
+  T* sigma = xw + (size_t)2 * np * RS;   // [n2]
+  T* xn = sigma + n2;                    // [2][np] squared norm of the column in flight
+  int* rank = (int*)(xn + 2 * np);       // [n2]
+  int* flag = rank + n2;                 // [4]
+  const int tid = threadIdx.x, proc = tid >> 3, g = tid & 7;
+  const bool act = proc < np;
+  const bool last = proc == np - 1;
+  vec_t pw[NC], qw[NC];
+  {
+    const int colp = 2 * proc, colq = 2 * proc + 1;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+      for (int z = 0; z < VW; ++z) {
+        const int row = (cc * 8 + g) * VW + z;
+        const bool ok = act && row < l;
+        pw[cc][z] = (ok && colp < l) ? c[(int64_t)colp * ldc + row] : (T)0;
+        qw[cc][z] = (ok && colq < l) ? c[(int64_t)colq * ldc + row] : (T)0;
+      }
+  }
+  const int my_off = proc * RS + g * VW;
+  const int up_proc = proc + 1 >= np ? 0 : proc + 1, dn_proc = proc == 0 ? np - 1 : proc - 1;
+  const int up_off = up_proc * RS + g * VW, dn_off = dn_proc * RS + g * VW;
+  T na = (T)0, nb = (T)0;
+  auto recompute_norms = [&]() {
+    vec_t va, vb;
+#pragma unroll
+    for (int z = 0; z < VW; ++z) va[z] = vb[z] = (T)0;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      va += pw[cc] * pw[cc];
+      vb += qw[cc] * qw[cc];
+    }
+    T a = va[0], b = vb[0];
+#pragma unroll
+    for (int z = 1; z < VW; ++z) {
+      a += va[z];
+      b += vb[z];
+    }
+    na = ring_sum8(a);
+    nb = ring_sum8(b);
+  };
+  // one round: rotate (P, Q), record the rotation, send `snd` (with its norm) and receive it from `src`
+  auto round = [&](bool forced, RotEntry<T>* rot_row, T* xwb, T* xnb, vec_t (&snd)[NC], T& nsnd, int src_off, int src_proc) {
+    vec_t vg;
+#pragma unroll
+    for (int z = 0; z < VW; ++z) vg[z] = (T)0;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) vg += pw[cc] * qw[cc];
+    T gg = vg[0];
+#pragma unroll
+    for (int z = 1; z < VW; ++z) gg += vg[z];
+    gg = ring_sum8(gg);
+    T rel = (T)0, t = (T)0, cs = (T)1, sn = (T)0;
+    const bool rot_now = !forced && jacobi_rotation(na, nb, gg, tol, cs, sn, rel, t);
+    if (rot_now) {
+      if (g == 0) {
+        flag[0] = 1;
+        if (rel > tol_early) flag[1] = 1;
+      }
+      na -= t * gg;
+      nb += t * gg;
+    } else {
+      cs = (T)1;
+      sn = (T)0;
+    }
+    if (act && g == 0) rot_row[proc] = RotEntry<T>{cs, sn};  // the pseudo pair is recorded as the identity
+    if (forced) {  // P <- -Q, Q <- P
+      cs = (T)0;
+      sn = (T)1;
+      const T tmp = na;
+      na = nb;
+      nb = tmp;
+    }
+    if (sn != (T)0) {
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        const vec_t x = pw[cc], y = qw[cc];
+        pw[cc] = cs * x - sn * y;
+        qw[cc] = sn * x + cs * y;
+      }
+    }
+    if (act) {
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) *(vec_t*)(xwb + my_off + cc * 8 * VW) = snd[cc];
+      if (g == 0) xnb[proc] = nsnd;
+    }
+    // LDS-only barrier: the rotation-stream store above must stay in flight (__syncthreads waits on vmcnt too)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (act) {
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) snd[cc] = *(const vec_t*)(xwb + src_off + cc * 8 * VW);
+      nsnd = xnb[src_proc];
+    }
+  };
+  int sweep = 0;
+  int rounds = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid < 2) flag[tid] = 0;
+    recompute_norms();
+    __syncthreads();
+    for (int r2 = 0; r2 < np; ++r2, rounds += 2) {
+      // even round: send Q to processor i - 1, receive Q from i + 1
+      round(false, rot + (size_t)rounds * kRingProcPad, xw, xn, qw, nb, up_off, up_proc);
+      // odd round: send P to i + 1, receive P from i - 1 (other buffer: one barrier per round is enough)
+      round(last, rot + (size_t)(rounds + 1) * kRingProcPad, xw + (size_t)np * RS, xn + np, pw, na, dn_off, dn_proc);
+    }
+    __syncthreads();
+    const int rotated = flag[0], big = flag[1];
+    __syncthreads();
+    if (!rotated || !big) {
+      ++sweep;  // this sweep's rounds are in the stream whether or not it rotated anything
+      break;
+    }
+  }
+  // Column ids by position: every completed sweep reverses the line order.  The zero padding column of an odd l
+  // (id l) must sort last even against exact-zero singular values.
+  {
+    T a = 0, b = 0;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+      for (int z = 0; z < VW; ++z) {
+        a += pw[cc][z] * pw[cc][z];
+        b += qw[cc][z] * qw[cc][z];
+      }
+    a = ring_sum8(a);
+    b = ring_sum8(b);
+    const int nsw = rounds / n2;
+    const int idp = (nsw & 1) ? n2 - 1 - 2 * proc : 2 * proc;
+    const int idq = (nsw & 1) ? n2 - 2 - 2 * proc : 2 * proc + 1;
+    if (act && g == 0) {
+      sigma[2 * proc] = idp < l ? sqrt(a) : (T)-1;
+      sigma[2 * proc + 1] = idq < l ? sqrt(b) : (T)-1;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < n2; j += blockDim.x) {
+    const T sj = sigma[j];
+    int r = 0;
+    for (int i = 0; i < n2; ++i) {
+      const T si = sigma[i];
+      r += (si > sj || (si == sj && i < j)) ? 1 : 0;
+    }
+    rank[j] = r;
+    rank_g[j] = r;
+  }
+  __syncthreads();
+  if (act) {
+    const int rp = rank[2 * proc], rq = rank[2 * proc + 1];
+    const T sp = sigma[2 * proc], sq = sigma[2 * proc + 1];
+    const T ip = sp > (T)0 ? (T)1 / sp : (T)0, iq = sq > (T)0 ? (T)1 / sq : (T)0;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+      for (int z = 0; z < VW; ++z) {
+        const int row = (cc * 8 + g) * VW + z;
+        if (row < l) {
+          if (rp < k) m2[(int64_t)rp * ld2 + row] = pw[cc][z] * ip;
+          if (rq < k) m2[(int64_t)rq * ld2 + row] = qw[cc][z] * iq;
+        }
+      }
+    if (g == 0) {
+      if (rp < k) s_out[rp] = sp > (T)0 ? sp : (T)0;
+      if (rq < k) s_out[rq] = sq > (T)0 ? sq : (T)0;
+    }
+  }
+  if (tid == 0) {
+    info[0] = sweep;
+    info[1] = rounds;
+  }
+}
+__host__ __device__ inline size_t jacobi_ring_w_lds_bytes(int l, int e, size_t esz) {
+  const int n2 = (l + 1) & ~1;
+  return (size_t)2 * (n2 / 2) * 8 * e * esz + (size_t)n2 * (esz + sizeof(int)) + (size_t)n2 * esz + 64;
+}
+
+// V_c[:, :k] from the recorded rotation stream: 8 lanes per row of V, 18 line positions per lane, 32 rows per
+// workgroup.  Round semantics (identical to the ring kernels): pair (first, second) = positions (2i, 2i + 1) in
+// even rounds, (2i + 1, 2i + 2) in odd rounds; first <- sn x + cs y, second <- cs x - sn y (rotation, then the two
+// columns swap positions); in odd rounds positions n - 1 and 0 are idle and position 0 changes sign (the pseudo
+// pair of the last processor).
+constexpr int kReplayChunk = 16;  // rounds staged in LDS at a time
+constexpr int kReplayLanes = 16;  // lanes per row of V (one DPP row); 10 line positions per lane
+// value of the previous / next lane inside the 16-lane DPP row (the 8-lane groups are row-aligned)
+__device__ __forceinline__ float dpp_from_prev(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_next(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double dpp_from_prev(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x111, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x111, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_next(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x101, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x101, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <class T>
+__global__ __launch_bounds__(256) void jacobi_replay_v_kernel(const RotEntry<T>* __restrict__ rot, const int* __restrict__ info,
+                                                              const int* __restrict__ rank_g, int l, int k, T* m1,
+                                                              int64_t ld1) {
+  constexpr int GL = kReplayLanes, NPL = 10, NPR = NPL / 2;  // GL * NPL = 160 positions >= 144
+  constexpr int ROWS = 256 / GL;                             // rows of V per workgroup
+  constexpr int kReplayRow = GL * (NPR + 1);                 // staged entries per round (one pad entry per lane)
+  typedef typename MT<T>::vec_t vec_t;
+  constexpr int VW = MT<T>::VEC;
+  constexpr int EV = (2 * (NPR + 1)) / VW;  // 16-byte vectors holding one lane's staged entries
+  static_assert((2 * (NPR + 1)) % VW == 0, "lane entries must fill whole 16-byte vectors");
+  __shared__ __attribute__((aligned(16))) RotEntry<T> stage[2][kReplayChunk][kReplayRow];
+  const int n2 = (l + 1) & ~1, np = n2 >> 1;
+  const int nrounds = info[1];
+  const int tid = threadIdx.x, ln = tid % GL, row = blockIdx.x * ROWS + tid / GL;
+  T v[NPL];
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) v[j] = (ln * NPL + j == row && row < l) ? (T)1 : (T)0;
+  const int nchunks = (nrounds + kReplayChunk - 1) / kReplayChunk;
+  constexpr int PER_THREAD = (kReplayChunk * kRingProcPad + 255) / 256;
+  RotEntry<T> pre[PER_THREAD];
+  auto fetch = [&](int chunk) {
+#pragma unroll
+    for (int q = 0; q < PER_THREAD; ++q) {
+      const int idx = tid + 256 * q;
+      const int64_t gidx = (int64_t)chunk * kReplayChunk * kRingProcPad + idx;
+      const bool ok = idx < kReplayChunk * kRingProcPad && gidx < (int64_t)nrounds * kRingProcPad;
+      pre[q] = ok ? rot[gidx] : RotEntry<T>{(T)1, (T)0};
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < PER_THREAD; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < kReplayChunk * kRingProcPad) {
+        const int rr = idx / kRingProcPad, i = idx - rr * kRingProcPad;
+        stage[buf][rr][(i / NPR) * (NPR + 1) + i % NPR] = pre[q];
+      }
+    }
+  };
+  // validity of this lane's pairs (even rounds: i < np; odd rounds: i < np - 1)
+  const int i0 = ln * NPR;
+  if (nchunks > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunks) fetch(ch + 1);
+    const int r_hi = min(kReplayChunk, nrounds - ch * kReplayChunk);
+    vec_t cur[EV], nxt[EV];
+    T pcs = (T)1, psn = (T)0, ncs = (T)1, nsn = (T)0;  // boundary pair of the previous lane
+    auto load_round = [&](int rr, vec_t (&dst)[EV], T& bcs, T& bsn) {
+      const vec_t* src = (const vec_t*)&stage[buf][rr][ln * (NPR + 1)];
+#pragma unroll
+      for (int q = 0; q < EV; ++q) dst[q] = src[q];
+      const RotEntry<T> pb = stage[buf][rr][ln > 0 ? (ln - 1) * (NPR + 1) + NPR - 1 : 0];
+      bcs = pb.cs;
+      bsn = pb.sn;
+    };
+    if (r_hi > 0) load_round(0, cur, pcs, psn);
+    for (int rr = 0; rr < r_hi; ++rr) {
+      if (rr + 1 < r_hi) load_round(rr + 1, nxt, ncs, nsn);
+      auto ecs = [&](int j) { return cur[(2 * j) / VW][(2 * j) % VW]; };
+      auto esn = [&](int j) { return cur[(2 * j + 1) / VW][(2 * j + 1) % VW]; };
+      if (((ch * kReplayChunk + rr) & 1) == 0) {
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+          const bool ok = i0 + j < np;
+          const T x = v[2 * j], y = v[2 * j + 1];
+          const T nx = esn(j) * x + ecs(j) * y, ny = ecs(j) * x - esn(j) * y;
+          v[2 * j] = ok ? nx : x;
+          v[2 * j + 1] = ok ? ny : y;
+        }
+      } else {
+        const T my_last = v[NPL - 1], my_first = v[0];
+        const T y_next = dpp_from_next(my_first);
+        const T x_prev = dpp_from_prev(my_last);
+#pragma unroll
+        for (int j = 0; j < NPR - 1; ++j) {
+          const bool ok = i0 + j < np - 1;
+          const T x = v[2 * j + 1], y = v[2 * j + 2];
+          const T nx = esn(j) * x + ecs(j) * y, ny = ecs(j) * x - esn(j) * y;
+          v[2 * j + 1] = ok ? nx : x;
+          v[2 * j + 2] = ok ? ny : y;
+        }
+        const T nl = esn(NPR - 1) * my_last + ecs(NPR - 1) * y_next;
+        v[NPL - 1] = (ln < GL - 1 && i0 + NPR - 1 < np - 1) ? nl : my_last;
+        const T nf = pcs * x_prev - psn * my_first;
+        v[0] = ln == 0 ? -my_first : ((i0 - 1 < np - 1) ? nf : my_first);
+      }
+#pragma unroll
+      for (int q = 0; q < EV; ++q) cur[q] = nxt[q];
+      pcs = ncs;
+      psn = nsn;
+    }
+    if (ch + 1 < nchunks) stash(buf ^ 1);
+    __syncthreads();
+  }
+  if (row < l) {
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int pos = ln * NPL + j;
+      if (pos < n2) {
+        const int r = rank_g[pos];
+        if (r < k) m1[(int64_t)r * ld1 + row] = v[j];
+      }
+    }
+  }
+}
+
 __host__ __device__ inline size_t jacobi_ring_lds_bytes(int l, int e, size_t esz) {
   const int n2 = (l + 1) & ~1;
   return (size_t)2 * (n2 / 2) * 8 * e * esz + (size_t)n2 * (esz + sizeof(int)) + (size_t)(n2 / 2) * esz + 64;
