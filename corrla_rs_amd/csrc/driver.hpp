@@ -154,6 +154,17 @@ struct RsvdDriver {
   // Returns the number of non-zero (orthonormal) columns.
   // `rough`: stop after the first clean Cholesky pass -- enough for the in-loop re-orthonormalisations
   // (random_svd.rs:37-39), whose only role is to keep the sketch well conditioned; the span is unchanged.
+  static constexpr int kStatusSlots = 64;
+  static constexpr size_t kStatusBytes = 32;  // one device status record (CholStatus)
+  struct Pending {
+    int slot, npass;
+    bool rough;
+  };
+  bool defer_status_ = false;
+  void* st_pool_ = nullptr;
+  int st_used_ = 0;
+  std::vector<Pending> pending_;
+
   int64_t orthonormalize(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough = false) {
     const int64_t l = y.cols;
     int64_t r = l;
@@ -167,7 +178,8 @@ struct RsvdDriver {
       const int npass = rough ? 1 : 2;
       Skinny<T> gd0 = dev.template alloc_skinny<T>(l, l);
       Skinny<T> md0 = dev.template alloc_skinny<T>(l, l);
-      void* st_dev = dev.alloc_bytes(128);
+      const bool defer = defer_status_ && st_used_ + npass <= kStatusSlots;
+      void* st_dev = defer ? (void*)((char*)st_pool_ + (size_t)st_used_ * kStatusBytes) : dev.alloc_bytes(2 * kStatusBytes);
       const double eps0 = (double)std::numeric_limits<T>::epsilon();
       for (int pass = 0; pass < npass; ++pass) {
         Skinny<T> yv = y.view_cols(l);
@@ -177,6 +189,14 @@ struct RsvdDriver {
         dev.gemm_tn(as_rowmajor_transposed(y, l), md0, tmp, kNone);
         std::swap(y.p, tmp.p);
         ++tm.qr_passes;
+      }
+      if (defer) {
+        // verified once at the end of random_svd_tall; a record that is not clean reruns the whole
+        // computation through the host-controlled path below
+        pending_.push_back({st_used_, npass, rough});
+        st_used_ += npass;
+        phase(tm.qr_gram_ms, qt0);
+        return l;
       }
       int fail[2] = {0, 0};
       float min_ratio[2], dev_i[2];
@@ -341,6 +361,43 @@ struct RsvdDriver {
   // u_tall: mt x k, v_tall: nt x k (both skinny, allocated by the caller), s_dev: k values (device).
   void random_svd_tall(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
                        T* s_dev, Skinny<T>& v_tall) {
+    if (dev.template device_chol_fits<T>(l)) {
+      // Optimistic run: every Cholesky-QR status record is checked once, after the last kernel is enqueued
+      // (no host synchronisation inside the call).  A record that is not clean (rank deficiency, zero or
+      // non-finite input, ...) repeats the computation with the host in the loop.
+      const Timings saved = tm;
+      st_pool_ = dev.alloc_bytes((size_t)kStatusSlots * kStatusBytes);
+      st_used_ = 0;
+      pending_.clear();
+      defer_status_ = true;
+      try {
+        random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
+      } catch (...) {
+        defer_status_ = false;
+        throw;
+      }
+      defer_status_ = false;
+      if (pending_clean()) return;
+      tm = saved;
+    }
+    random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
+  }
+
+  bool pending_clean() {
+    if (pending_.empty()) return true;
+    int fail[kStatusSlots];
+    float min_ratio[kStatusSlots], dev_i[kStatusSlots];
+    dev.read_chol_status(st_pool_, st_used_, fail, min_ratio, dev_i);
+    for (const Pending& p : pending_) {
+      const int f0 = fail[p.slot];
+      if (f0 != 0) return false;
+      if (!p.rough && (fail[p.slot + 1] != 0 || !(dev_i[p.slot + 1] <= 0.25f))) return false;
+    }
+    return true;
+  }
+
+  void random_svd_tall_body(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
+                            T* s_dev, Skinny<T>& v_tall) {
     PhaseTimer total;
     Skinny<T> q = dev.template alloc_skinny<T>(a.mt, l);
     Skinny<T> q2 = dev.template alloc_skinny<T>(a.mt, l);

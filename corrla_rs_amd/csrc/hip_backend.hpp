@@ -287,7 +287,9 @@ class HipDev {
     CORRLA_HIP(hipGetLastError());
   }
   void read_chol_status(const void* st_dev, int n, int* fail, float* min_ratio, float* dev_i) {
-    k::CholStatus h[4];
+    k::CholStatus h[64];
+    static_assert(sizeof(k::CholStatus) == 32, "driver.hpp assumes 32-byte status records");
+    if (n > 64) throw Error(ST_EINVAL, "internal: too many status records");
     CORRLA_HIP(hipMemcpyAsync(h, st_dev, sizeof(k::CholStatus) * n, hipMemcpyDeviceToHost, stream));
     sync();
     for (int i = 0; i < n; ++i) {

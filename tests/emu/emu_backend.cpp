@@ -167,6 +167,7 @@ class EmuDev {
   struct EmuCholStatus {
     int fail;
     float min_ratio, dev_i, gmax;
+    long long clk, wall;  // same 32-byte record as the device kernel's
   };
   template <class T>
   bool device_chol_fits(int64_t l) const {
