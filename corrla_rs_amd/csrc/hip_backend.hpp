@@ -674,7 +674,7 @@ class HipDev {
   // reduction is long enough to make up the workgroup count by splitting it.
   void choose_geometry(bool tn, int64_t outer_n, int nblk, int tiles_total, int* mw_out, int* nsplit_out) const {
     const int ov = tn ? split_tn_override_ : split_nn_override_;
-    int mw = (outer_n >= 128 && tiles_total >= 8) ? 2 : 1;
+    int mw = (outer_n >= 256 && tiles_total >= 8) ? 2 : 1;  // small outputs (Gram, core) use the MW = 1 instantiation
     if (mw_override_ > 0) mw = mw_override_;
     const int64_t outer_tiles = (outer_n + 64 * mw - 1) / (64 * mw);
     const int64_t wgs = outer_tiles * nblk;

@@ -1537,7 +1537,7 @@ __host__ __device__ inline size_t jacobi_ring_w_lds_bytes(int l, int e, size_t e
 // columns swap positions); in odd rounds positions n - 1 and 0 are idle and position 0 changes sign (the pseudo
 // pair of the last processor).
 constexpr int kReplayChunk = 16;  // rounds staged in LDS at a time
-constexpr int kReplayLanes = 16;  // lanes per row of V (one DPP row); 10 line positions per lane
+constexpr int kReplayLanes = 16;  // lanes per row of V (one DPP row): 10 line positions per lane (32 lanes: 6)
 // value of the previous / next lane inside the 16-lane DPP row (the 8-lane groups are row-aligned)
 __device__ __forceinline__ float dpp_from_prev(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
@@ -1559,7 +1559,8 @@ template <class T>
 __global__ __launch_bounds__(256) void jacobi_replay_v_kernel(const RotEntry<T>* __restrict__ rot, const int* __restrict__ info,
                                                               const int* __restrict__ rank_g, int l, int k, T* m1,
                                                               int64_t ld1) {
-  constexpr int GL = kReplayLanes, NPL = 10, NPR = NPL / 2;  // GL * NPL = 160 positions >= 144
+  constexpr int GL = kReplayLanes, NPL = GL == 16 ? 10 : 6, NPR = NPL / 2;  // GL * NPL >= 144 positions
+  static_assert(GL * NPL >= 2 * kRingProcPad, "positions");
   constexpr int ROWS = 256 / GL;                             // rows of V per workgroup
   constexpr int kReplayRow = GL * (NPR + 1);                 // staged entries per round (one pad entry per lane)
   typedef typename MT<T>::vec_t vec_t;
@@ -1606,51 +1607,58 @@ __global__ __launch_bounds__(256) void jacobi_replay_v_kernel(const RotEntry<T>*
     const int buf = ch & 1;
     if (ch + 1 < nchunks) fetch(ch + 1);
     const int r_hi = min(kReplayChunk, nrounds - ch * kReplayChunk);
-    vec_t cur[EV], nxt[EV];
-    T pcs = (T)1, psn = (T)0, ncs = (T)1, nsn = (T)0;  // boundary pair of the previous lane
-    auto load_round = [&](int rr, vec_t (&dst)[EV], T& bcs, T& bsn) {
+    // Rounds come in (even, odd) pairs (chunks start on an even round); the entries of the next round are
+    // loaded into the other register set while this one is applied, so no LDS latency sits between rounds.
+    vec_t ea[EV], eb[EV];
+    T acs = (T)1, asn = (T)0, bcs = (T)1, bsn = (T)0;  // boundary pair of the previous lane
+    auto load_round = [&](int rr, vec_t (&dst)[EV], T& pc, T& ps) {
       const vec_t* src = (const vec_t*)&stage[buf][rr][ln * (NPR + 1)];
 #pragma unroll
       for (int q = 0; q < EV; ++q) dst[q] = src[q];
       const RotEntry<T> pb = stage[buf][rr][ln > 0 ? (ln - 1) * (NPR + 1) + NPR - 1 : 0];
-      bcs = pb.cs;
-      bsn = pb.sn;
+      pc = pb.cs;
+      ps = pb.sn;
     };
-    if (r_hi > 0) load_round(0, cur, pcs, psn);
-    for (int rr = 0; rr < r_hi; ++rr) {
-      if (rr + 1 < r_hi) load_round(rr + 1, nxt, ncs, nsn);
-      auto ecs = [&](int j) { return cur[(2 * j) / VW][(2 * j) % VW]; };
-      auto esn = [&](int j) { return cur[(2 * j + 1) / VW][(2 * j + 1) % VW]; };
-      if (((ch * kReplayChunk + rr) & 1) == 0) {
+    auto even_round = [&](const vec_t (&e)[EV]) {
 #pragma unroll
-        for (int j = 0; j < NPR; ++j) {
-          const bool ok = i0 + j < np;
-          const T x = v[2 * j], y = v[2 * j + 1];
-          const T nx = esn(j) * x + ecs(j) * y, ny = ecs(j) * x - esn(j) * y;
-          v[2 * j] = ok ? nx : x;
-          v[2 * j + 1] = ok ? ny : y;
-        }
-      } else {
-        const T my_last = v[NPL - 1], my_first = v[0];
-        const T y_next = dpp_from_next(my_first);
-        const T x_prev = dpp_from_prev(my_last);
-#pragma unroll
-        for (int j = 0; j < NPR - 1; ++j) {
-          const bool ok = i0 + j < np - 1;
-          const T x = v[2 * j + 1], y = v[2 * j + 2];
-          const T nx = esn(j) * x + ecs(j) * y, ny = ecs(j) * x - esn(j) * y;
-          v[2 * j + 1] = ok ? nx : x;
-          v[2 * j + 2] = ok ? ny : y;
-        }
-        const T nl = esn(NPR - 1) * my_last + ecs(NPR - 1) * y_next;
-        v[NPL - 1] = (ln < GL - 1 && i0 + NPR - 1 < np - 1) ? nl : my_last;
-        const T nf = pcs * x_prev - psn * my_first;
-        v[0] = ln == 0 ? -my_first : ((i0 - 1 < np - 1) ? nf : my_first);
+      for (int j = 0; j < NPR; ++j) {
+        const T cs = e[(2 * j) / VW][(2 * j) % VW], sn = e[(2 * j + 1) / VW][(2 * j + 1) % VW];
+        const bool ok = i0 + j < np;
+        const T x = v[2 * j], y = v[2 * j + 1];
+        const T nx = sn * x + cs * y, ny = cs * x - sn * y;
+        v[2 * j] = ok ? nx : x;
+        v[2 * j + 1] = ok ? ny : y;
       }
+    };
+    auto odd_round = [&](const vec_t (&e)[EV], T pc, T ps) {
+      const T my_last = v[NPL - 1], my_first = v[0];
+      // neighbours' boundary values: DPP inside a 16-lane row, the LDS crossbar for 32-lane groups (issued
+      // first, consumed after the in-lane pairs)
+      const T y_next = GL <= 16 ? dpp_from_next(my_first) : __shfl_down(my_first, 1, GL);
+      const T x_prev = GL <= 16 ? dpp_from_prev(my_last) : __shfl_up(my_last, 1, GL);
 #pragma unroll
-      for (int q = 0; q < EV; ++q) cur[q] = nxt[q];
-      pcs = ncs;
-      psn = nsn;
+      for (int j = 0; j < NPR - 1; ++j) {
+        const T cs = e[(2 * j) / VW][(2 * j) % VW], sn = e[(2 * j + 1) / VW][(2 * j + 1) % VW];
+        const bool ok = i0 + j < np - 1;
+        const T x = v[2 * j + 1], y = v[2 * j + 2];
+        const T nx = sn * x + cs * y, ny = cs * x - sn * y;
+        v[2 * j + 1] = ok ? nx : x;
+        v[2 * j + 2] = ok ? ny : y;
+      }
+      const T lcs = e[(2 * (NPR - 1)) / VW][(2 * (NPR - 1)) % VW], lsn = e[(2 * NPR - 1) / VW][(2 * NPR - 1) % VW];
+      const T nl = lsn * my_last + lcs * y_next;
+      v[NPL - 1] = (ln < GL - 1 && i0 + NPR - 1 < np - 1) ? nl : my_last;
+      const T nf = pc * x_prev - ps * my_first;
+      v[0] = ln == 0 ? -my_first : ((i0 - 1 < np - 1) ? nf : my_first);
+    };
+    if (r_hi > 0) load_round(0, ea, acs, asn);
+    for (int rr = 0; rr < r_hi; rr += 2) {
+      if (rr + 1 < r_hi) load_round(rr + 1, eb, bcs, bsn);
+      even_round(ea);
+      if (rr + 1 < r_hi) {
+        if (rr + 2 < r_hi) load_round(rr + 2, ea, acs, asn);
+        odd_round(eb, bcs, bsn);
+      }
     }
     if (ch + 1 < nchunks) stash(buf ^ 1);
     __syncthreads();
@@ -2003,8 +2011,12 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
         if (own && ti == tj) *(V4*)&rb[k0] = V4{v[aj][0], v[aj][1], v[aj][2], v[aj][3]};
         if (own && tk == tj) *(V4*)&cb[i0] = V4{w[0][aj], w[1][aj], w[2][aj], w[3][aj]};
         __syncthreads();
+        // every LDS read of the step is issued before the pivot test (one LDS round trip per step)
         const T d = rb[j];
         const T g0 = diag0[j];
+        const V4 rk4 = *(const V4*)&rb[k0];
+        const V4 ri4 = *(const V4*)&rb[i0];
+        const V4 ci4 = *(const V4*)&cb[i0];
         if (!(d > piv_rel * g0) || !(g0 > (T)0)) {
           fl = 1;  // uniform: every thread reads the same d
           break;
@@ -2020,12 +2032,10 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
         if (own && tk >= tj) {  // tiles left of the pivot column are finished
           T rinv = fast_rcp(d);
           rinv = rinv * ((T)2 - d * rinv);
-          const V4 rk4 = *(const V4*)&rb[k0];
           T rk[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) rk[q] = rk4[q] * rinv;
           if (ti >= tj) {
-            const V4 ri4 = *(const V4*)&rb[i0];
             T ri[4] = {ri4[0], ri4[1], ri4[2], ri4[3]};
             if (ti == tj) {
 #pragma unroll
@@ -2037,7 +2047,6 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
               for (int b = 0; b < 4; ++b) v[aa][b] -= ri[aa] * rk[b];
           }
           if (ti <= tj) {
-            const V4 ci4 = *(const V4*)&cb[i0];
             T ci[4] = {ci4[0], ci4[1], ci4[2], ci4[3]};
             if (ti == tj) {
 #pragma unroll

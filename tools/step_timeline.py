@@ -29,15 +29,23 @@ def main():
         for n, (c, t) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
             print(f"{n:72s} {c:6d} {t / 1e3:10.1f} {t / 1e3 / c:9.2f} {100.0 * t / allns:6.2f}")
         return
-    # a step starts with the Philox fill of Omega when present, else with the first big gemm_nn after a copy_out
-    big = [i for i, r in enumerate(rows) if "gemm_nn" in r[0] and (r[2] - r[1]) > 300000]
-    ends = [i for i, r in enumerate(rows) if "copy_out_kernel" in r[0]]
-    if not big or not ends:
-        print("no rsvd step found")
+    # one rsvd call ends with column_sign + apply_column_sign x2 + copy_out x2; --call N picks the N-th call
+    # (default: the 5th, a timed step of the default bench run after its 3 warm-up calls)
+    call = 5
+    if "--call" in sys.argv:
+        call = int(sys.argv[sys.argv.index("--call") + 1])
+    signs = [i for i, r in enumerate(rows) if "column_sign_kernel" in r[0] and "apply" not in r[0]]
+    if len(signs) < call or call < 2:
+        print("not enough rsvd calls in the trace")
         return
-    last_end = ends[-1]
-    prev_end = max(i for i in ends if i < last_end - 5)
-    seg = rows[prev_end + 1:last_end + 1]
+    def call_end(i):
+        j = i
+        while j + 1 < len(rows) and ("copy_out" in rows[j + 1][0] or "apply_column_sign" in rows[j + 1][0]):
+            j += 1
+        return j
+    first = call_end(signs[call - 2]) + 1
+    last = call_end(signs[call - 1])
+    seg = rows[first:last + 1]
     t0 = seg[0][1]
     pe = seg[0][1]
     total = 0
