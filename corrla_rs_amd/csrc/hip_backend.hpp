@@ -398,7 +398,11 @@ class HipDev {
     constexpr size_t kLdsMax = (size_t)160 * 1024;
     const size_t lds2 = k::jacobi_lds_bytes((int)l, sizeof(T), true);
     const size_t lds1 = k::jacobi_lds_bytes((int)l, sizeof(T), false);
-    if (lds1 > kLdsMax || l > k::kJacobiMaxL) {
+    const bool ring_ok = l >= 2 && l <= 144 && !env_int("CORRLA_JACOBI_NORING", 0) &&
+                         k::jacobi_ring_w_lds_bytes((int)l, l <= 64 ? 8 : (l <= 96 ? 12 : (l <= 128 ? 16 : (sizeof(T) == 4 ? 20 : 18))),
+                                                    sizeof(T)) <= kLdsMax;
+    // the LDS-resident kernels with V in global memory are far slower than the block kernel
+    if (!ring_ok && (lds2 > kLdsMax || l > k::kJacobiMaxL)) {
       small_svd_block(c, l, k, m1, m2, s_dev);
       return;
     }
@@ -411,11 +415,15 @@ class HipDev {
     const bool v_lds = lds2 <= kLdsMax;
     const size_t lds = v_lds ? lds2 : lds1;
     // ring kernel: columns resident in registers (l <= 144)
-    if (l >= 2 && l <= 144 && !env_int("CORRLA_JACOBI_NORING", 0)) {
+    const int ring_e = l <= 64 ? 8 : (l <= 96 ? 12 : (l <= 128 ? 16 : (sizeof(T) == 4 ? 20 : 18)));
+    const bool ring_replay = !env_int("CORRLA_JACOBI_NOREPLAY", 0);
+    const size_t ring_lds = ring_replay ? k::jacobi_ring_w_lds_bytes((int)l, ring_e, sizeof(T))
+                                        : k::jacobi_ring_lds_bytes((int)l, ring_e, sizeof(T));
+    if (l >= 2 && l <= 144 && ring_lds <= kLdsMax && !env_int("CORRLA_JACOBI_NORING", 0)) {
       const int np = (int)((l + 1) / 2);
-      const dim3 block((unsigned)round_up(np * 8, 64));
+      const dim3 block((unsigned)(np * 8));  // a partial last wave: no idle processors, no LDS slots for them
       const int max_sw = env_int("CORRLA_JACOBI_SWEEPS", 40);
-      const bool replay = !env_int("CORRLA_JACOBI_NOREPLAY", 0);
+      const bool replay = ring_replay;
       const int n2 = 2 * np;
       k::RotEntry<T>* rot = nullptr;
       int* rank_g = nullptr;

@@ -1353,10 +1353,12 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
   constexpr int RS = 8 * E;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n2 = (l + 1) & ~1, np = n2 >> 1;
-  T* xw = (T*)smem;                      // [2][np][RS] W column in flight (double-buffered)
-  T* sigma = xw + (size_t)2 * np * RS;   // [n2]
-  T* xn = sigma + n2;                    // [2][np] squared norm of the column in flight
-  int* rank = (int*)(xn + 2 * np);       // [n2]
+  const int nproc = blockDim.x >> 3;     // processors incl. the idle ones of the last wave: all own LDS slots, so
+                                         // the round body needs no "active" guards
+  T* xw = (T*)smem;                      // [2][nproc][RS] W column in flight (double-buffered)
+  T* sigma = xw + (size_t)2 * nproc * RS;  // [n2]
+  T* xn = sigma + n2;                    // [2][nproc] squared norm of the column in flight
+  int* rank = (int*)(xn + 2 * nproc);    // [n2]
   int* flag = rank + n2;                 // [4]
   const int tid = threadIdx.x, proc = tid >> 3, g = tid & 7;
   const bool act = proc < np;
@@ -1375,7 +1377,8 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
       }
   }
   const int my_off = proc * RS + g * VW;
-  const int up_proc = proc + 1 >= np ? 0 : proc + 1, dn_proc = proc == 0 ? np - 1 : proc - 1;
+  // idle processors (proc >= np) form their own harmless ring of zero columns
+  const int up_proc = act ? (proc + 1 >= np ? 0 : proc + 1) : proc, dn_proc = act ? (proc == 0 ? np - 1 : proc - 1) : proc;
   const int up_off = up_proc * RS + g * VW, dn_off = dn_proc * RS + g * VW;
   T na = (T)0, nb = (T)0;
   auto recompute_norms = [&]() {
@@ -1420,7 +1423,7 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
       cs = (T)1;
       sn = (T)0;
     }
-    if (act && g == 0) rot_row[proc] = RotEntry<T>{cs, sn};  // the pseudo pair is recorded as the identity
+    if (g == 0) rot_row[proc] = RotEntry<T>{cs, sn};  // the pseudo pair is recorded as the identity
     if (forced) {  // P <- -Q, Q <- P
       cs = (T)0;
       sn = (T)1;
@@ -1428,26 +1431,21 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
       na = nb;
       nb = tmp;
     }
-    if (sn != (T)0) {
+    // unconditional: (cs, sn) = (1, 0) is exact, and a branch would only pay off when all 8 processors of a wave skip
 #pragma unroll
-      for (int cc = 0; cc < NC; ++cc) {
-        const vec_t x = pw[cc], y = qw[cc];
-        pw[cc] = cs * x - sn * y;
-        qw[cc] = sn * x + cs * y;
-      }
+    for (int cc = 0; cc < NC; ++cc) {
+      const vec_t x = pw[cc], y = qw[cc];
+      pw[cc] = cs * x - sn * y;
+      qw[cc] = sn * x + cs * y;
     }
-    if (act) {
 #pragma unroll
-      for (int cc = 0; cc < NC; ++cc) *(vec_t*)(xwb + my_off + cc * 8 * VW) = snd[cc];
-      if (g == 0) xnb[proc] = nsnd;
-    }
+    for (int cc = 0; cc < NC; ++cc) *(vec_t*)(xwb + my_off + cc * 8 * VW) = snd[cc];
+    if (g == 0) xnb[proc] = nsnd;
     // LDS-only barrier: the rotation-stream store above must stay in flight (__syncthreads waits on vmcnt too)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (act) {
 #pragma unroll
-      for (int cc = 0; cc < NC; ++cc) snd[cc] = *(const vec_t*)(xwb + src_off + cc * 8 * VW);
-      nsnd = xnb[src_proc];
-    }
+    for (int cc = 0; cc < NC; ++cc) snd[cc] = *(const vec_t*)(xwb + src_off + cc * 8 * VW);
+    nsnd = xnb[src_proc];
   };
   int sweep = 0;
   int rounds = 0;
@@ -1459,7 +1457,7 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
       // even round: send Q to processor i - 1, receive Q from i + 1
       round(false, rot + (size_t)rounds * kRingProcPad, xw, xn, qw, nb, up_off, up_proc);
       // odd round: send P to i + 1, receive P from i - 1 (other buffer: one barrier per round is enough)
-      round(last, rot + (size_t)(rounds + 1) * kRingProcPad, xw + (size_t)np * RS, xn + np, pw, na, dn_off, dn_proc);
+      round(last, rot + (size_t)(rounds + 1) * kRingProcPad, xw + (size_t)nproc * RS, xn + nproc, pw, na, dn_off, dn_proc);
     }
     __syncthreads();
     const int rotated = flag[0], big = flag[1];
@@ -1528,7 +1526,8 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
 }
 __host__ __device__ inline size_t jacobi_ring_w_lds_bytes(int l, int e, size_t esz) {
   const int n2 = (l + 1) & ~1;
-  return (size_t)2 * (n2 / 2) * 8 * e * esz + (size_t)n2 * (esz + sizeof(int)) + (size_t)n2 * esz + 64;
+  const int nproc = n2 / 2;  // launched with exactly 8 * np threads
+  return (size_t)2 * nproc * 8 * e * esz + (size_t)n2 * (esz + sizeof(int)) + (size_t)2 * nproc * esz + 64;
 }
 
 // V_c[:, :k] from the recorded rotation stream: 8 lanes per row of V, 18 line positions per lane, 32 rows per
