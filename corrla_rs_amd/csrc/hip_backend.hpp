@@ -333,10 +333,13 @@ class HipDev {
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, 12>, attr, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, 16>, attr, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_kernel<T, BIG_E>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 8>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 12>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 16>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, BIG_E>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 8, 8>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 12, 8>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 16, 8>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, BIG_E, 8>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 24, 4>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 32, 4>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_ring_w_kernel<T, 36, 4>, attr, 160 * 1024));
   }
 
   // SVD of the l x l core (random_svd.rs:89).  Default: single-workgroup LDS-resident Jacobi when W fits
@@ -399,8 +402,7 @@ class HipDev {
     const size_t lds2 = k::jacobi_lds_bytes((int)l, sizeof(T), true);
     const size_t lds1 = k::jacobi_lds_bytes((int)l, sizeof(T), false);
     const bool ring_ok = l >= 2 && l <= 144 && !env_int("CORRLA_JACOBI_NORING", 0) &&
-                         k::jacobi_ring_w_lds_bytes((int)l, l <= 64 ? 8 : (l <= 96 ? 12 : (l <= 128 ? 16 : (sizeof(T) == 4 ? 20 : 18))),
-                                                    sizeof(T)) <= kLdsMax;
+                         k::jacobi_ring_w_lds_bytes((int)l, l <= 96 ? 96 : (l <= 128 ? 128 : 144), sizeof(T)) <= kLdsMax;
     // the LDS-resident kernels with V in global memory are far slower than the block kernel
     if (!ring_ok && (lds2 > kLdsMax || l > k::kJacobiMaxL)) {
       small_svd_block(c, l, k, m1, m2, s_dev);
@@ -415,13 +417,18 @@ class HipDev {
     const bool v_lds = lds2 <= kLdsMax;
     const size_t lds = v_lds ? lds2 : lds1;
     // ring kernel: columns resident in registers (l <= 144)
-    const int ring_e = l <= 64 ? 8 : (l <= 96 ? 12 : (l <= 128 ? 16 : (sizeof(T) == 4 ? 20 : 18)));
+    // ring kernels: rows per column slot = G lanes x E rows.  G = 4 (fewer, longer waves) measured ~12 % slower
+    // than G = 8 at l = 96..144 (latency is hidden by the extra waves); kept behind CORRLA_RING_G4 for experiments
     const bool ring_replay = !env_int("CORRLA_JACOBI_NOREPLAY", 0);
-    const size_t ring_lds = ring_replay ? k::jacobi_ring_w_lds_bytes((int)l, ring_e, sizeof(T))
-                                        : k::jacobi_ring_lds_bytes((int)l, ring_e, sizeof(T));
+    const int ring_g = (ring_replay && l > 64 && env_int("CORRLA_RING_G4", 0)) ? 4 : 8;
+    const int ring_e8 = l <= 64 ? 8 : (l <= 96 ? 12 : (l <= 128 ? 16 : (sizeof(T) == 4 ? 20 : 18)));
+    const int ring_e4 = l <= 96 ? 24 : (l <= 128 ? 32 : 36);
+    const int ring_rs = ring_g == 4 ? 4 * ring_e4 : 8 * ring_e8;
+    const size_t ring_lds = ring_replay ? k::jacobi_ring_w_lds_bytes((int)l, ring_rs, sizeof(T))
+                                        : k::jacobi_ring_lds_bytes((int)l, ring_e8, sizeof(T));
     if (l >= 2 && l <= 144 && ring_lds <= kLdsMax && !env_int("CORRLA_JACOBI_NORING", 0)) {
       const int np = (int)((l + 1) / 2);
-      const dim3 block((unsigned)(np * 8));  // a partial last wave: no idle processors, no LDS slots for them
+      const dim3 block((unsigned)(np * ring_g));  // a partial last wave: no idle processors, no LDS slots for them
       const int max_sw = env_int("CORRLA_JACOBI_SWEEPS", 40);
       const bool replay = ring_replay;
       const int n2 = 2 * np;
@@ -431,22 +438,29 @@ class HipDev {
         rot = (k::RotEntry<T>*)alloc_bytes((size_t)max_sw * n2 * k::kRingProcPad * sizeof(k::RotEntry<T>));
         rank_g = (int*)alloc_bytes(sizeof(int) * (size_t)n2);
       }
+#define CORRLA_RING_W(EE, GG)                                                                                       \
+  hipLaunchKernelGGL((k::jacobi_ring_w_kernel<T, EE, GG>), dim3(1), block, ring_lds, stream, (const T*)c.p, c.ld, (int)l, \
+                     m2.p, m2.ld, s_dev, (int)k, tol, tol_early, max_sw, rot, rank_g, info)
 #define CORRLA_RING(EE)                                                                                                  \
-  do {                                                                                                                   \
-    if (replay)                                                                                                          \
-      hipLaunchKernelGGL((k::jacobi_ring_w_kernel<T, EE>), dim3(1), block, k::jacobi_ring_w_lds_bytes((int)l, EE, sizeof(T)), \
-                         stream, (const T*)c.p, c.ld, (int)l, m2.p, m2.ld, s_dev, (int)k, tol, tol_early, max_sw, rot,     \
-                         rank_g, info);                                                                                  \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((k::jacobi_ring_kernel<T, EE>), dim3(1), block, k::jacobi_ring_lds_bytes((int)l, EE, sizeof(T)), \
-                         stream, (const T*)c.p, c.ld, (int)l, m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, tol_early,    \
-                         max_sw, info);                                                                                  \
-  } while (0)
+  hipLaunchKernelGGL((k::jacobi_ring_kernel<T, EE>), dim3(1), block, ring_lds, stream, (const T*)c.p, c.ld, (int)l, m1.p, \
+                     m1.ld, m2.p, m2.ld, s_dev, (int)k, tol, tol_early, max_sw, info)
       constexpr int kBigE = sizeof(T) == 4 ? 20 : 18;
-      if (l <= 64) CORRLA_RING(8);
-      else if (l <= 96) CORRLA_RING(12);
-      else if (l <= 128) CORRLA_RING(16);
-      else CORRLA_RING(kBigE);
+      if (replay && ring_g == 4) {
+        if (l <= 96) CORRLA_RING_W(24, 4);
+        else if (l <= 128) CORRLA_RING_W(32, 4);
+        else CORRLA_RING_W(36, 4);
+      } else if (replay) {
+        if (l <= 64) CORRLA_RING_W(8, 8);
+        else if (l <= 96) CORRLA_RING_W(12, 8);
+        else if (l <= 128) CORRLA_RING_W(16, 8);
+        else CORRLA_RING_W(kBigE, 8);
+      } else {
+        if (l <= 64) CORRLA_RING(8);
+        else if (l <= 96) CORRLA_RING(12);
+        else if (l <= 128) CORRLA_RING(16);
+        else CORRLA_RING(kBigE);
+      }
+#undef CORRLA_RING_W
 #undef CORRLA_RING
       CORRLA_HIP(hipGetLastError());
       if (replay) {

@@ -1106,6 +1106,31 @@ __device__ __forceinline__ double ring_sum8(double x) {
   x += dpp(x, std::integral_constant<int, 0x141>{});
   return x;
 }
+template <int G>
+__device__ __forceinline__ float ring_sum(float x) {
+  static_assert(G == 4 || G == 8, "lanes per processor");
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{});  // quad_perm [1,0,3,2]
+  x += dpp(x, std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]
+  if constexpr (G == 8) x += dpp(x, std::integral_constant<int, 0x141>{});  // row_half_mirror
+  return x;
+}
+template <int G>
+__device__ __forceinline__ double ring_sum(double x) {
+  static_assert(G == 4 || G == 8, "lanes per processor");
+  auto dpp = [](double v, auto ctrl) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, decltype(ctrl)::value, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, decltype(ctrl)::value, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{});
+  x += dpp(x, std::integral_constant<int, 0x4E>{});
+  if constexpr (G == 8) x += dpp(x, std::integral_constant<int, 0x141>{});
+  return x;
+}
 constexpr int kRingMaxThreads = 576;  // 72 processors x 8 lanes
 template <class T, int E>
 __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_kernel(const T* __restrict__ c, int64_t ldc, int l, T* m1,
@@ -1341,8 +1366,8 @@ template <class T>
 struct RotEntry {
   T cs, sn;
 };
-template <class T, int E>
-__global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T* __restrict__ c, int64_t ldc, int l, T* m2,
+template <class T, int E, int G>
+__global__ __launch_bounds__(kRingProcPad * G) void jacobi_ring_w_kernel(const T* __restrict__ c, int64_t ldc, int l, T* m2,
                                                                         int64_t ld2, T* s_out, int k, T tol, T tol_early,
                                                                         int max_sweeps, RotEntry<T>* rot, int* rank_g,
                                                                         int* info) {
@@ -1350,17 +1375,17 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
   constexpr int VW = MT<T>::VEC;
   static_assert(E % VW == 0, "whole 16-byte chunks per lane");
   constexpr int NC = E / VW;
-  constexpr int RS = 8 * E;
+  constexpr int RS = G * E;  // padded column length
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n2 = (l + 1) & ~1, np = n2 >> 1;
-  const int nproc = blockDim.x >> 3;     // processors incl. the idle ones of the last wave: all own LDS slots, so
+  const int nproc = blockDim.x / G;      // processors incl. the idle ones of the last wave: all own LDS slots, so
                                          // the round body needs no "active" guards
   T* xw = (T*)smem;                      // [2][nproc][RS] W column in flight (double-buffered)
   T* sigma = xw + (size_t)2 * nproc * RS;  // [n2]
   T* xn = sigma + n2;                    // [2][nproc] squared norm of the column in flight
   int* rank = (int*)(xn + 2 * nproc);    // [n2]
   int* flag = rank + n2;                 // [4]
-  const int tid = threadIdx.x, proc = tid >> 3, g = tid & 7;
+  const int tid = threadIdx.x, proc = tid / G, g = tid % G;
   const bool act = proc < np;
   const bool last = proc == np - 1;
   vec_t pw[NC], qw[NC];
@@ -1370,7 +1395,7 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
     for (int cc = 0; cc < NC; ++cc)
 #pragma unroll
       for (int z = 0; z < VW; ++z) {
-        const int row = (cc * 8 + g) * VW + z;
+        const int row = (cc * G + g) * VW + z;
         const bool ok = act && row < l;
         pw[cc][z] = (ok && colp < l) ? c[(int64_t)colp * ldc + row] : (T)0;
         qw[cc][z] = (ok && colq < l) ? c[(int64_t)colq * ldc + row] : (T)0;
@@ -1396,8 +1421,8 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
       a += va[z];
       b += vb[z];
     }
-    na = ring_sum8(a);
-    nb = ring_sum8(b);
+    na = ring_sum<G>(a);
+    nb = ring_sum<G>(b);
   };
   // one round: rotate (P, Q), record the rotation, send `snd` (with its norm) and receive it from `src`
   auto round = [&](bool forced, RotEntry<T>* rot_row, T* xwb, T* xnb, vec_t (&snd)[NC], T& nsnd, int src_off, int src_proc) {
@@ -1409,7 +1434,7 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
     T gg = vg[0];
 #pragma unroll
     for (int z = 1; z < VW; ++z) gg += vg[z];
-    gg = ring_sum8(gg);
+    gg = ring_sum<G>(gg);
     T rel = (T)0, t = (T)0, cs = (T)1, sn = (T)0;
     const bool rot_now = !forced && jacobi_rotation(na, nb, gg, tol, cs, sn, rel, t);
     if (rot_now) {
@@ -1439,12 +1464,12 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
       qw[cc] = sn * x + cs * y;
     }
 #pragma unroll
-    for (int cc = 0; cc < NC; ++cc) *(vec_t*)(xwb + my_off + cc * 8 * VW) = snd[cc];
+    for (int cc = 0; cc < NC; ++cc) *(vec_t*)(xwb + my_off + cc * G * VW) = snd[cc];
     if (g == 0) xnb[proc] = nsnd;
     // LDS-only barrier: the rotation-stream store above must stay in flight (__syncthreads waits on vmcnt too)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-    for (int cc = 0; cc < NC; ++cc) snd[cc] = *(const vec_t*)(xwb + src_off + cc * 8 * VW);
+    for (int cc = 0; cc < NC; ++cc) snd[cc] = *(const vec_t*)(xwb + src_off + cc * G * VW);
     nsnd = xnb[src_proc];
   };
   int sweep = 0;
@@ -1478,8 +1503,8 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
         a += pw[cc][z] * pw[cc][z];
         b += qw[cc][z] * qw[cc][z];
       }
-    a = ring_sum8(a);
-    b = ring_sum8(b);
+    a = ring_sum<G>(a);
+    b = ring_sum<G>(b);
     const int nsw = rounds / n2;
     const int idp = (nsw & 1) ? n2 - 1 - 2 * proc : 2 * proc;
     const int idq = (nsw & 1) ? n2 - 2 - 2 * proc : 2 * proc + 1;
@@ -1508,7 +1533,7 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
     for (int cc = 0; cc < NC; ++cc)
 #pragma unroll
       for (int z = 0; z < VW; ++z) {
-        const int row = (cc * 8 + g) * VW + z;
+        const int row = (cc * G + g) * VW + z;
         if (row < l) {
           if (rp < k) m2[(int64_t)rp * ld2 + row] = pw[cc][z] * ip;
           if (rq < k) m2[(int64_t)rq * ld2 + row] = qw[cc][z] * iq;
@@ -1524,10 +1549,11 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_w_kernel(const T*
     info[1] = rounds;
   }
 }
-__host__ __device__ inline size_t jacobi_ring_w_lds_bytes(int l, int e, size_t esz) {
+// rs = G * E: rows per column slot
+__host__ __device__ inline size_t jacobi_ring_w_lds_bytes(int l, int rs, size_t esz) {
   const int n2 = (l + 1) & ~1;
-  const int nproc = n2 / 2;  // launched with exactly 8 * np threads
-  return (size_t)2 * nproc * 8 * e * esz + (size_t)n2 * (esz + sizeof(int)) + (size_t)2 * nproc * esz + 64;
+  const int nproc = n2 / 2;  // launched with exactly G * np threads
+  return (size_t)2 * nproc * rs * esz + (size_t)n2 * (esz + sizeof(int)) + (size_t)2 * nproc * esz + 64;
 }
 
 // V_c[:, :k] from the recorded rotation stream: 8 lanes per row of V, 18 line positions per lane, 32 rows per
