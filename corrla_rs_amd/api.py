@@ -87,12 +87,13 @@ class Context:
         return {f: getattr(t, f) for f, _ in t._fields_ if f != "reserved"}
 
     # ---- helpers -----------------------------------------------------------------------
-    def _opts(self, seed, omega, nt, l, dtype, on_device):
-        if seed is None and omega is None:
+    def _opts(self, seed, omega, nt, l, dtype, on_device, extra_flags=0):
+        if seed is None and omega is None and not extra_flags:
             return None, None
         o = L.Opts()
         o.struct_size = C.sizeof(L.Opts)
         o.seed = int(seed) if seed is not None else 0
+        o.flags = int(extra_flags)
         keep = None
         if omega is not None:
             if on_device:
@@ -103,7 +104,7 @@ class Context:
                     raise ValueError(f"omega must have shape {(nt, l)}, got {tuple(om.shape)}")
                 keep = om.t().contiguous()  # (l, nt) row-major == (nt, l) column-major
                 o.omega = keep.data_ptr()
-                o.flags = L.OMEGA_ON_DEVICE
+                o.flags |= L.OMEGA_ON_DEVICE
             else:
                 om = np.asarray(omega, dtype=dtype)
                 if om.shape != (nt, l):
@@ -181,10 +182,15 @@ class Context:
         return self._rsvd_torch(a_local, int(n_rank), int(n_iters), int(n_oversamples), seed, omega, sharded=True)
 
     # ---- PCA caller (pca_rsvd.rs:56-82) ---------------------------------------------------
-    def pca(self, x_mat, rank, n_iter=None, n_oversamples=None, *, seed=None, omega=None):
+    def pca(self, x_mat, rank, n_iter=None, n_oversamples=None, *, seed=None, omega=None, center=None):
         """PcaRsvd::new(x, rank): returns (means (1, n), singular values (k, 1), components (k, n)).
-        n_iter / n_oversamples default to the reference's hard-coded 20 / min(n_dim, 10) (pca_rsvd.rs:65-66)."""
+        n_iter / n_oversamples default to the reference's hard-coded 20 / min(n_dim, 10) (pca_rsvd.rs:65-66).
+        center: None (library default: implicit rank-1 corrections for f64, a centred copy for f32), "fused" or
+        "copy" (CORRLA_PCA_CENTER_* in include/corrla_rsvd.h)."""
         rank = int(rank)
+        if center not in (None, "fused", "copy"):
+            raise ValueError("center must be None, 'fused' or 'copy'")
+        cflags = {None: 0, "fused": L.PCA_CENTER_FUSED, "copy": L.PCA_CENTER_COPY}[center]
         if _is_torch(x_mat) and x_mat.is_cuda:
             import torch
             x = x_mat if x_mat.dtype in (torch.float32, torch.float64) else x_mat.to(torch.float64)
@@ -196,7 +202,7 @@ class Context:
             rs, cs = x.stride()
             nt = min(m, n)
             l = min(rank + max(p, 0), nt)
-            o, keep = self._opts(seed, omega, nt, l, x.dtype, True)
+            o, keep = self._opts(seed, omega, nt, l, x.dtype, True, cflags)
             kk = max(rank, 1)
             means = torch.empty((1, n), dtype=x.dtype, device=x.device)
             s = torch.empty((kk, 1), dtype=x.dtype, device=x.device)
@@ -219,7 +225,7 @@ class Context:
         p = min(n, 10) if n_oversamples is None else int(n_oversamples)
         nt = min(m, n)
         l = min(rank + max(p, 0), nt)
-        o, keep = self._opts(seed, omega, nt, l, x.dtype, False)
+        o, keep = self._opts(seed, omega, nt, l, x.dtype, False, cflags)
         kk = max(rank, 1)
         means = np.empty((1, n), dtype=x.dtype)
         s = np.empty((kk, 1), dtype=x.dtype)

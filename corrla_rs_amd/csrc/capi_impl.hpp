@@ -43,6 +43,9 @@ inline RunOpts parse_opts(const corrla_opts* o, bool dev_ptrs) {
   r.omega_ld = o->omega_ld;
   r.omega_on_device = (o->flags & CORRLA_OMEGA_ON_DEVICE) != 0;
   if (r.omega_on_device && !dev_ptrs) throw Error(ST_EINVAL, "CORRLA_OMEGA_ON_DEVICE is only valid for *_dev entry points");
+  if ((o->flags & CORRLA_PCA_CENTER_FUSED) && (o->flags & CORRLA_PCA_CENTER_COPY))
+    throw Error(ST_EINVAL, "CORRLA_PCA_CENTER_FUSED and CORRLA_PCA_CENTER_COPY are mutually exclusive");
+  r.pca_center = (o->flags & CORRLA_PCA_CENTER_FUSED) ? 1 : ((o->flags & CORRLA_PCA_CENTER_COPY) ? 2 : 0);
   return r;
 }
 
@@ -162,7 +165,8 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
   if (tm_out) *tm_out = drv.tm;
 }
 
-// PcaRsvd::new (pca_rsvd.rs:56-82): means, centred copy, random_svd of the centred matrix; keeps S and V^T.
+// PcaRsvd::new (pca_rsvd.rs:56-82): means, centring (implicit rank-1 corrections or a centred copy, see
+// CORRLA_PCA_CENTER_*), random_svd of the centred matrix; keeps S and V^T.
 template <class Dev, class T>
 inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank,
                       int64_t n_iter, int64_t n_oversamples, const corrla_opts* opts, T* means, T* s, T* comps,
@@ -189,19 +193,29 @@ inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n
     drv.at_times(ta, ones, mu, inv_m, false);  // mu (n) = x^T 1 / m
   else
     drv.a_times(ta, ones, mu, inv_m);          // tall view = x^T (n x m): mu (n) = x^T 1 / m
-  // centred copy (center_mat_col clones too, mat_utils.rs:484): memory rows/cols of the staged operand
-  const int64_t ldp = round_up(ta.mem.cols, kLdPad);
-  T* cbuf = (T*)dev.alloc_bytes((size_t)ta.mem.rows * (size_t)ldp * sizeof(T));
-  dev.memset_zero(cbuf, (size_t)ta.mem.rows * (size_t)ldp * sizeof(T));
-  // data columns run along the memory columns iff (tall & row-major) or (fat & column-major-as-rows ...):
-  // tall view element (i, j): row-major memory (i, j), else memory (j, i).  Data column index of x is j for
-  // the tall case and i for the fat case.
-  const bool mean_along_mem_cols = (ta.row_major != fat);
-  dev.center_rows_cols(ta.mem.p, ta.mem.rows, ta.mem.cols, ta.mem.ld, mu.p, mean_along_mem_cols, cbuf, ldp);
   TallA<T> tc = ta;
-  tc.mem.p = cbuf;
-  tc.mem.ld = ldp;
-  tc.mem.cols_readable = ldp;
+  const bool fused = ro.pca_center == 1 || (ro.pca_center == 0 && sizeof(T) == 8);
+  if (fused) {
+    // the centred matrix is never formed.  Tall view (i, j) = x(i, j) for tall inputs (means run
+    // along the SHORT side), = x(j, i) for fat inputs (means run along the TALL side).
+    if (!fat)
+      tc.mu_short = mu.p;
+    else
+      tc.mu_tall = mu.p;
+  } else {
+    // centred copy (center_mat_col clones too, mat_utils.rs:484): memory rows/cols of the staged operand
+    const int64_t ldp = round_up(ta.mem.cols, kLdPad);
+    T* cbuf = (T*)dev.alloc_bytes((size_t)ta.mem.rows * (size_t)ldp * sizeof(T));
+    dev.memset_zero(cbuf, (size_t)ta.mem.rows * (size_t)ldp * sizeof(T));
+    // data columns run along the memory columns iff (tall & row-major) or (fat & column-major-as-rows ...):
+    // tall view element (i, j): row-major memory (i, j), else memory (j, i).  Data column index of x is j for
+    // the tall case and i for the fat case.
+    const bool mean_along_mem_cols = (ta.row_major != fat);
+    dev.center_rows_cols(ta.mem.p, ta.mem.rows, ta.mem.cols, ta.mem.ld, mu.p, mean_along_mem_cols, cbuf, ldp);
+    tc.mem.p = cbuf;
+    tc.mem.ld = ldp;
+    tc.mem.cols_readable = ldp;
+  }
   const int64_t k = rank;
   const int64_t l = std::min<int64_t>(rank + n_oversamples, tc.nt);
   if (ro.omega && ro.omega_ld < tc.nt) throw Error(ST_EINVAL, "omega_ld < min(m, n)");

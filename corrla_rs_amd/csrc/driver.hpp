@@ -83,6 +83,10 @@ struct TallA {
   Big<T> mem;
   bool row_major = true;
   int64_t mt = 0, nt = 0;  // local rows (sharded) x columns
+  // Implicit centring (PCA): the operator is A - 1 mu_short^T (mu_short: nt values, device) or
+  // A - mu_tall 1^T (mu_tall: mt values); A itself is never rewritten.  At most one of them is set.
+  const T* mu_short = nullptr;
+  const T* mu_tall = nullptr;
 };
 
 struct RunOpts {
@@ -91,6 +95,7 @@ struct RunOpts {
   int64_t omega_ld = 0;
   bool omega_on_device = false;
   bool sharded = false;  // rows of A are sharded over the communicator
+  int pca_center = 0;    // 0 default, 1 fused, 2 centred copy (corrla_pca_* only)
 };
 
 struct Timings {
@@ -131,6 +136,12 @@ struct RsvdDriver {
       dev.gemm_nn(a.mem, x, y, scale_dev);
     else
       dev.gemm_tn(a.mem, x, y, scale_dev);
+    if (a.mu_short || a.mu_tall) {
+      // (A - 1 mu^T) X = A X - 1 (mu^T X);  (A - mu 1^T) X = A X - mu (1^T X)
+      T* v = dev.template alloc_scalar<T>((int)x.cols_alloc);
+      dev.weighted_colsum(x, a.nt, a.mu_short, v);
+      dev.rank1_sub(y, a.mt, a.mu_tall, v, scale_dev);
+    }
   }
   // Z (nt x L) = scale * A^T * Y (mt x L); all-reduced when rows are sharded   random_svd.rs:42-46,80
   void at_times(const TallA<T>& a, const Skinny<T>& y, Skinny<T>& z, const T* scale_dev, bool sharded) {
@@ -138,6 +149,13 @@ struct RsvdDriver {
       dev.gemm_tn(a.mem, y, z, scale_dev);
     else
       dev.gemm_nn(a.mem, y, z, scale_dev);
+    if (a.mu_short || a.mu_tall) {
+      if (sharded) throw Error(ST_EINVAL, "internal: implicit centring is not available for sharded inputs");
+      // (A - 1 mu^T)^T Y = A^T Y - mu (1^T Y);  (A - mu 1^T)^T Y = A^T Y - 1 (mu^T Y)
+      T* v = dev.template alloc_scalar<T>((int)y.cols_alloc);
+      dev.weighted_colsum(y, a.mt, a.mu_tall, v);
+      dev.rank1_sub(z, a.nt, a.mu_short, v, scale_dev);
+    }
     if (sharded) dev.allreduce(z.p, (size_t)z.ld * (size_t)z.cols_alloc);
   }
 

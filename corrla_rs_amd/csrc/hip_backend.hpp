@@ -545,6 +545,26 @@ class HipDev {
     CORRLA_HIP(hipGetLastError());
   }
 
+  // ---- implicit centring ---------------------------------------------------------
+  template <class T>
+  void weighted_colsum(const Skinny<T>& x, int64_t rows, const T* w, T* v) {
+    const int ncols = (int)x.cols_alloc;
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(64, (rows + 4095) / 4096));
+    double* partial = (double*)alloc_bytes(sizeof(double) * (size_t)nblk * (size_t)ncols);
+    hipLaunchKernelGGL((k::wcolsum_partial_kernel<T>), dim3((unsigned)nblk, (unsigned)ncols), dim3(256), 0, stream,
+                       (const T*)x.p, x.ld, rows, w, partial, ncols);
+    hipLaunchKernelGGL((k::wcolsum_final_kernel<T>), dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, stream,
+                       (const double*)partial, nblk, ncols, v);
+    CORRLA_HIP(hipGetLastError());
+  }
+  template <class T>
+  void rank1_sub(Skinny<T>& out, int64_t rows, const T* u, const T* v, const T* scale) {
+    dim3 grid((unsigned)((rows + 255) / 256), (unsigned)out.cols_alloc);
+    check_grid(grid);
+    hipLaunchKernelGGL((k::rank1_sub_kernel<T>), grid, dim3(256), 0, stream, out.p, out.ld, rows, u, v, scale);
+    CORRLA_HIP(hipGetLastError());
+  }
+
   // sign convention: flip (u_i, v_i) so the largest-magnitude entry of v_i is positive
   template <class T>
   void fix_signs(Skinny<T>& v_ref, Skinny<T>& other, int64_t k) {

@@ -2157,6 +2157,43 @@ __global__ void center_kernel(const T* in, int64_t rows, int64_t cols, int64_t l
   }
 }
 
+// ---- implicit centring: rank-1 corrections of the products with A - 1 mu^T ----------------
+// partial[b][c] = sum over this block's rows of (w ? w[r] : 1) * x(r, c), f64 accumulation, fixed order
+template <class T>
+__global__ __launch_bounds__(256) void wcolsum_partial_kernel(const T* __restrict__ x, int64_t ld, int64_t rows,
+                                                              const T* __restrict__ w, double* partial, int ncols) {
+  __shared__ double red[256];
+  const int c = blockIdx.y;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+  double s = 0.0;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) s += (w ? (double)w[r] : 1.0) * (double)x[(int64_t)c * ld + r];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * ncols + c] = red[0];
+}
+template <class T>
+__global__ void wcolsum_final_kernel(const double* partial, int nblk, int ncols, T* v) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * ncols + c];
+  v[c] = (T)s;
+}
+// out(i, c) -= scale * (u ? u[i] : 1) * v[c]
+template <class T>
+__global__ void rank1_sub_kernel(T* out, int64_t ld, int64_t rows, const T* __restrict__ u, const T* __restrict__ v,
+                                 const T* __restrict__ scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const T sc = scale ? *scale : (T)1;
+  out[(int64_t)blockIdx.y * ld + i] -= sc * (u ? u[i] : (T)1) * v[blockIdx.y];
+}
+
 // ---- sign convention of the singular triplets ---------------------------------------------------
 // The reference leaves the signs of (u_i, v_i) to faer's SVD.  Here triplet i is normalised so that the
 // largest-magnitude component (first one on ties) of column i of the SHORT-side factor V_tall (n_t rows,

@@ -56,6 +56,13 @@ typedef enum corrla_status {
 
 /* opts.flags */
 #define CORRLA_OMEGA_ON_DEVICE 0x1u /* opts.omega is a device pointer (only for *_dev entry points) */
+/* corrla_pca_*: how the column centring of center_mat_col (mat_utils.rs:482-502) is applied.
+ * FUSED: the matrix is never rewritten; every product with the centred matrix is corrected by a rank-1 term,
+ *        (A - 1 mu^T) X = A X - 1 (mu^T X), (A - 1 mu^T)^T Y = A^T Y - mu (1^T Y)  (SURVEY section 8 f1).
+ * COPY : a centred copy is formed first, as the reference does (one more m x n buffer).
+ * Default (neither flag): FUSED for f64, COPY for f32 (the fused form cancels digits when |mean| >> spread). */
+#define CORRLA_PCA_CENTER_FUSED 0x2u
+#define CORRLA_PCA_CENTER_COPY 0x4u
 
 /*
  * Options block.  Zero-initialise, set struct_size = sizeof(corrla_opts).  NULL opts == defaults.

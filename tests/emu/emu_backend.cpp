@@ -285,6 +285,22 @@ class EmuDev {
     for (int64_t r = 0; r < rows; ++r)
       for (int64_t c = 0; c < cols; ++c) out[r * ldo + c] = in[r * ldi + c] - (along_cols ? mu[c] : mu[r]);
   }
+  // v[c] = sum_{r < rows} (w ? w[r] : 1) x(r, c) for every allocated column of x
+  template <class T>
+  void weighted_colsum(const Skinny<T>& x, int64_t rows, const T* w, T* v) {
+    for (int64_t c = 0; c < x.cols_alloc; ++c) {
+      double s = 0.0;
+      for (int64_t r = 0; r < rows; ++r) s += (w ? (double)w[r] : 1.0) * (double)x.p[c * x.ld + r];
+      v[c] = (T)s;
+    }
+  }
+  // out(i, c) -= scale * (u ? u[i] : 1) * v[c]
+  template <class T>
+  void rank1_sub(Skinny<T>& out, int64_t rows, const T* u, const T* v, const T* scale) {
+    const T sc = scale ? *scale : (T)1;
+    for (int64_t c = 0; c < out.cols_alloc; ++c)
+      for (int64_t r = 0; r < rows; ++r) out.p[c * out.ld + r] -= sc * (u ? u[r] : (T)1) * v[c];
+  }
   template <class T>
   void sumsq(const Skinny<T>& y, double* out) {
     double s = 0.0;

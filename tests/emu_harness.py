@@ -120,7 +120,8 @@ def emu_fill_normal(rows, cols, seed, dtype=np.float64, row0=0, global_cols=None
     return out
 
 
-def emu_pca(x, rank, q, p, omega=None):
+def emu_pca(x, rank, q, p, omega=None, center=None):
+    """center: None (library default), "fused" (CORRLA_PCA_CENTER_FUSED = 0x2) or "copy" (0x4)."""
     e = emu()
     x = np.asarray(x)
     suf = "f32" if x.dtype == np.float32 else "f64"
@@ -129,6 +130,10 @@ def emu_pca(x, rank, q, p, omega=None):
     nt = min(m, n)
     l = min(rank + p, nt)
     o, keep = _opts(omega, nt, l, x.dtype)
+    if center is not None:
+        if o is None:
+            o, keep = _opts(np.random.default_rng(0).standard_normal((nt, l)), nt, l, x.dtype)
+        o.flags |= {"fused": 0x2, "copy": 0x4, "both": 0x6}[center]
     means = np.empty((1, n), dtype=x.dtype)
     s = np.empty((rank, 1), dtype=x.dtype)
     comps = np.empty((rank, n), dtype=x.dtype, order="F")

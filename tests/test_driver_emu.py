@@ -164,6 +164,27 @@ def test_fill_normal_is_counter_based_and_standard_normal():
 
 
 @pytest.mark.parametrize("shape", [(100, 10), (60, 90), (300, 40)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_emu_pca_fused_centring_equals_centred_copy(shape, dtype):
+    """(A - 1 mu^T) X = A X - 1 (mu^T X) and its transpose, against the centred copy the reference
+    forms (center_mat_col, mat_utils.rs:482-502); tall and fat inputs take different correction vectors."""
+    rng = np.random.default_rng(sum(shape) + 1)
+    m, n = shape
+    x = (rng.standard_normal((m, n)) * (0.8 ** np.arange(n)) + rng.standard_normal((1, n)) * 0.5).astype(dtype)
+    k, p = 4, min(n, 10)
+    nt = min(m, n)
+    omega = rng.standard_normal((nt, min(k + p, nt))).astype(dtype)
+    mf, sf, cf = emu_pca(x, k, 20, p, omega=omega, center="fused")
+    mc, sc, cc = emu_pca(x, k, 20, p, omega=omega, center="copy")
+    f64 = dtype == np.float64
+    assert np.array_equal(mf, mc)
+    assert np.allclose(sf, sc, rtol=1e-10 if f64 else 2e-4)
+    assert np.linalg.norm(cf.T.astype(np.float64) @ cf - cc.T.astype(np.float64) @ cc) < (1e-8 if f64 else 5e-3)
+    with pytest.raises(ValueError):
+        emu_pca(x, k, 20, p, omega=omega, center="both")
+
+
+@pytest.mark.parametrize("shape", [(100, 10), (60, 90), (300, 40)])
 @pytest.mark.parametrize("order", ["C", "F"])
 def test_emu_pca_matches_oracle(shape, order):
     """PcaRsvd::new (pca_rsvd.rs:56-82) through the real glue: means, centring, random_svd(cx, k, 20, min(n,10))."""

@@ -385,6 +385,26 @@ def test_pca_matches_oracle_and_sklearn(ctx, shape, dtype):
     assert np.allclose((s.astype(np.float64) ** 2 / (m - 1.0)).ravel(), sk.explained_variance_, rtol=1e-6 if f64 else 1e-3)
 
 
+@pytest.mark.parametrize("shape", [(3000, 96), (64, 1500)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pca_fused_centring_equals_centred_copy(ctx, shape, dtype):
+    """implicit centring (rank-1 corrections, the matrix is never rewritten) against the centred copy."""
+    rng = np.random.default_rng(sum(shape))
+    m, n = shape
+    x = (rng.standard_normal((m, n)) * (0.97 ** np.arange(n)) + rng.standard_normal((1, n)) * 0.5).astype(dtype)
+    k, p = 6, 10
+    nt = min(m, n)
+    omega = rng.standard_normal((nt, k + p)).astype(dtype)
+    mf, sf, cf = ctx.pca(x, k, omega=omega, center="fused")
+    mc, sc, cc = ctx.pca(x, k, omega=omega, center="copy")
+    f64 = dtype == np.float64
+    assert np.array_equal(mf, mc)
+    assert np.allclose(sf, sc, rtol=1e-10 if f64 else 2e-4)
+    assert np.linalg.norm(cf.T.astype(np.float64) @ cf - cc.T.astype(np.float64) @ cc) < (1e-8 if f64 else 5e-3)
+    mo, so, co, _ = orc.pca_rsvd(x.astype(np.float64), k, omega=omega.astype(np.float64))
+    assert np.allclose(sf, so, rtol=1e-9 if f64 else 2e-4)
+
+
 def test_rpca_surface_ignores_iters_and_oversamples_like_the_reference(ctx):
     # lib_math_utils_py.rs:38-55: rpca(a, n_rank, n_iters, n_oversamples) -> (singular_values (k,1), components (k,n))
     import corrla_rs as hrl
