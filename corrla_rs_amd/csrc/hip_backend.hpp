@@ -97,6 +97,7 @@ class HipDev {
     if (stream) (void)hipStreamSynchronize(stream);
     if (comm) (void)ncclCommDestroy(comm);
     for (auto& c : chunks_) (void)hipFree(c.p);
+    for (auto& c : zchunks_) (void)hipFree(c.p);
     if (zero_page_) (void)hipFree(zero_page_);
     if (pinned_) (void)hipHostFree(pinned_);
     for (auto& e : events_)
@@ -127,6 +128,13 @@ class HipDev {
     CORRLA_HIP(hipSetDevice(device));
     events_set_[0] = events_set_[1] = false;
     for (auto& c : chunks_) c.used = 0;
+    // zero pool: the part the previous call used is cleared by ONE memset per chunk (capped), instead of one
+    // small memset per workspace allocation
+    for (auto& c : zchunks_) {
+      c.zeroed = std::min<size_t>(c.used, (size_t)256 << 20);
+      c.used = 0;
+      if (c.zeroed) CORRLA_HIP(hipMemsetAsync(c.p, 0, c.zeroed, stream));
+    }
   }
   void end_call() { sync(); }
   void sync() { CORRLA_HIP(hipStreamSynchronize(stream)); }
@@ -151,6 +159,35 @@ class HipDev {
     return c.p;
   }
   void memset_zero(void* p, size_t bytes) { CORRLA_HIP(hipMemsetAsync(p, 0, bytes, stream)); }
+  // zero-filled workspace from the zero pool
+  void* alloc_zeroed(size_t bytes) {
+    bytes = (bytes + 255) / 256 * 256;
+    if (bytes == 0) bytes = 256;
+    Chunk* hit = nullptr;
+    for (auto& c : zchunks_)
+      if (c.size - c.used >= bytes) {
+        hit = &c;
+        break;
+      }
+    if (!hit) {
+      Chunk c;
+      c.size = std::max<size_t>(bytes, (size_t)128 << 20);
+      if (hipMalloc(&c.p, c.size) != hipSuccess) {
+        (void)hipGetLastError();
+        throw Error(ST_ENOMEM, "device allocation of " + std::to_string(c.size) + " bytes failed");
+      }
+      zchunks_.push_back(c);
+      hit = &zchunks_.back();
+    }
+    char* p = (char*)hit->p + hit->used;
+    const size_t end = hit->used + bytes;
+    if (end > hit->zeroed) {  // beyond what begin_call cleared
+      const size_t from = std::max(hit->used, hit->zeroed);
+      CORRLA_HIP(hipMemsetAsync((char*)hit->p + from, 0, end - from, stream));
+    }
+    hit->used = end;
+    return p;
+  }
 
   template <class T>
   Skinny<T> alloc_skinny(int64_t rows, int64_t cols) {
@@ -160,20 +197,15 @@ class HipDev {
     s.ld = round_up(std::max<int64_t>(rows, 1), kLdPad);
     s.cols_alloc = col_blocking(cols).cols_alloc;
     const size_t bytes = (size_t)s.ld * (size_t)s.cols_alloc * sizeof(T);
-    s.p = (T*)alloc_bytes(bytes);
-    memset_zero(s.p, bytes);
+    s.p = (T*)alloc_zeroed(bytes);
     return s;
   }
   double* alloc_f64(int n) {
-    double* p = (double*)alloc_bytes(sizeof(double) * n);
-    memset_zero(p, sizeof(double) * n);
-    return p;
+    return (double*)alloc_zeroed(sizeof(double) * n);
   }
   template <class T>
   T* alloc_scalar(int n) {
-    T* p = (T*)alloc_bytes(sizeof(T) * n);
-    memset_zero(p, sizeof(T) * n);
-    return p;
+    return (T*)alloc_zeroed(sizeof(T) * n);
   }
 
   void h2d_2d(void* dst, int64_t dpitch_e, const void* src, int64_t spitch_e, int64_t width_e, int64_t rows, size_t esz) {
@@ -664,8 +696,10 @@ class HipDev {
   struct Chunk {
     void* p = nullptr;
     size_t size = 0, used = 0;
+    size_t zeroed = 0;  // zero pool only: bytes cleared by begin_call
   };
   std::vector<Chunk> chunks_;
+  std::vector<Chunk> zchunks_;  // zero pool (alloc_zeroed)
   void* zero_page_ = nullptr;
   void* pinned_ = nullptr;  // staging for the small l x l transfers
   hipEvent_t events_[2] = {nullptr, nullptr};

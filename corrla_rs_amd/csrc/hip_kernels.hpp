@@ -2024,6 +2024,33 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
   int fl = bad ? 3 : (!(g2 > 0.f) ? 2 : 0);
   float min_ratio = 1.f;
   const long long clk0 = clock64(), wall0 = wall_clock64();
+  // G = I + E with a tiny E (the polishing pass of CholeskyQR2): (I + E)^(-1/2) = I - E/2 + 3E^2/8 - ..., and
+  // 3 ||E||^2 / 8 is below eps / 4, so the symmetric first-order factor replaces the elimination (uniform branch).
+  const float series_tol = sizeof(T) == 4 ? 2.0e-4f : 1.0e-8f;
+  if (fl == 0 && d2 <= series_tol) {
+    if (own) {
+#pragma unroll
+      for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int i = i0 + aa, k = k0 + b;
+          if (i < r && k < r) {
+            const T val = (i == k ? (T)1 : (T)0) - (T)0.5 * (v[aa][b] - (i == k ? (T)1 : (T)0));
+            m[(int64_t)k * ldm + i] = val;
+            m[(int64_t)i * ldm + k] = val;
+          }
+        }
+    }
+    if (tid == 0) {
+      st->fail = 0;
+      st->min_ratio = 1.f;
+      st->dev_i = d2;
+      st->gmax = g2;
+      st->clk = 0;
+      st->wall = 0;
+    }
+    return;
+  }
   if (fl == 0) {
     typedef T V4 __attribute__((ext_vector_type(4)));
     for (int tj = 0; tj < nt && fl == 0; ++tj) {

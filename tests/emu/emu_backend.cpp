@@ -199,6 +199,13 @@ class EmuDev {
       st->fail = 2;
       return;
     }
+    if (dv <= (sizeof(T) == 4 ? 2.0e-4 : 1.0e-8)) {  // polishing pass: (I + E)^(-1/2) = I - E/2 to below eps
+      for (int64_t j = 0; j < r; ++j)
+        for (int64_t i = 0; i < r; ++i)
+          m_out.p[j * m_out.ld + i] = (T)((i == j ? 1.0 : 0.0) - 0.5 * (a[j * r + i] - (i == j ? 1.0 : 0.0)));
+      st->fail = 0;
+      return;
+    }
     double mr = 0.0;
     // the device kernel factorizes in T precision: round G through T first
     if (!small::chol_upper((int)r, a.data(), (int)r, (double)piv_rel, &mr)) {
