@@ -330,6 +330,50 @@ def test_f64_core_sizes_cross_kernel_boundaries(ctx, l_total):
     assert orth_err(u) < 1e-11 and orth_err(vt.T) < 1e-11
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_core_widths_across_every_kernel_boundary(ctx, dtype):
+    """l = k + p swept over the selection boundaries of the device kernels: ring Jacobi register variants (64 / 96 /
+    128 / 144, odd widths carry a zero padding column through the ring), LDS-resident and block Jacobi beyond,
+    device Cholesky + inverse (l <= 176) vs the host-controlled path.  Same Omega as the oracle."""
+    rng = np.random.default_rng(7)
+    m, n = 420, 230
+    # spectrum decays to 0.16 sigma_1: (sigma_l / sigma_1)^(2q+1) stays far above f32 eps, so every triplet is
+    # determined by the data and not by rounding in the power iteration
+    a = (rng.standard_normal((m, n)) * (0.992 ** np.arange(n))).astype(dtype)
+    f64 = dtype == np.float64
+    widths = (1, 2, 3, 4, 5, 8, 9, 17, 31, 63, 64, 65, 95, 96, 97, 127, 128, 129, 137, 143, 144, 145, 161, 176, 177, 201, 230)
+    for l in widths:
+        if l == n and not f64:
+            continue  # l = n: cond(Y) = (sigma_1 / sigma_n)^5 exceeds 1 / eps_f32, the f32 tail is rounding noise
+        p = min(10, l - 1)
+        k = l - p
+        om = rng.standard_normal((n, l)).astype(dtype)
+        u, s, vt = ctx.rsvd(a, k, 2, p, omega=om)
+        uo, so, vto = orc.random_svd(a.astype(np.float64), k, 2, p, omega=om.astype(np.float64))
+        assert np.max(np.abs(s.astype(np.float64) - so)) <= (1e-10 if f64 else 1e-4) * so[0, 0], l
+        assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= (1e-9 if f64 else 1e-5), l
+        assert orth_err(u) < (1e-11 if f64 else 2e-4) and orth_err(vt.T) < (1e-11 if f64 else 2e-4), l
+        assert np.all(np.diff(s.ravel()) <= 0) and np.all(s >= 0), l
+
+
+@pytest.mark.parametrize("env", ["CORRLA_JACOBI_NOREPLAY", "CORRLA_JACOBI_NORING", "CORRLA_RING_G4", "CORRLA_HOST_CHOL"])
+def test_alternative_device_paths_agree(ctx, env, monkeypatch):
+    """The full ring kernel (V accumulated in the kernel), the LDS-resident kernels, the 4-lane ring variant and the
+    host-controlled Cholesky-QR must reproduce the default path (W-only ring + replay, device Cholesky)."""
+    rng = np.random.default_rng(11)
+    a = (rng.standard_normal((600, 150)) * (0.98 ** np.arange(150))).astype(np.float32)
+    for l in (75, 138):   # odd pair count / the C2 width
+        om = rng.standard_normal((150, l)).astype(np.float32)
+        u0, s0, vt0 = ctx.rsvd(a, l - 10, 2, 10, omega=om)
+        monkeypatch.setenv(env, "1")
+        u1, s1, vt1 = ctx.rsvd(a, l - 10, 2, 10, omega=om)
+        monkeypatch.delenv(env)
+        assert np.max(np.abs(s1 - s0)) <= 3e-5 * s0[0, 0]
+        rec0 = (u0.astype(np.float64) * s0.ravel()) @ vt0.astype(np.float64)
+        rec1 = (u1.astype(np.float64) * s1.ravel()) @ vt1.astype(np.float64)
+        assert np.linalg.norm(rec1 - rec0) <= 2e-3 * np.linalg.norm(rec0)
+
+
 def test_non_finite_input_is_an_error_not_garbage(ctx):
     from corrla_rs_amd._lib import CorrlaError
     a = np.ones((64, 32))
