@@ -54,6 +54,9 @@ def _sigs():
         s["corrla_fill_normal_dev_" + suf] = (C.c_int, [vp, vp, i64, i64, i64, i64, u64, i64, i64])
         s["corrla_time_sketch_dev_" + suf] = (C.c_int, [vp, vp, i64, i64, i64, i64, vp, i64, i64, vp, i64, C.c_int,
                                                          C.POINTER(dbl)])
+    grad = [vp, vp, i64, i64, vp, vp, i64, C.c_int, i64, dbl, vp, i64, C.POINTER(C.c_int)]
+    s["corrla_grad_mat_f64"] = (C.c_int, grad)
+    s["corrla_grad_mat_dev_f64"] = (C.c_int, grad)
     return s
 
 

@@ -236,6 +236,38 @@ class Context:
         del keep
         return means, s, comps
 
+    # ---- active-subspace gradient stage ---------------------------------------
+    def grad_mat(self, x_mat, y, est_order, n_nbrs, x_query=None, *, scale=1.0):
+        """``ActiveSsRsvd::create_grad_mat`` with a ``PolyGradientEstimator(x_mat, y, est_order, n_nbrs)``
+        (active_subspaces.rs:66-141, 215-229): returns (G, n_regularised) with G the k x n_q gradient matrix (column i =
+        gradient at query i; queries default to the support points), scaled by `scale`.  numpy in -> numpy out;
+        torch CUDA tensors in -> torch CUDA tensor out (no host copies)."""
+        est_order, n_nbrs = int(est_order), int(n_nbrs)
+        nreg = C.c_int(0)
+        if _is_torch(x_mat) and x_mat.is_cuda:
+            import torch
+            x = x_mat.to(torch.float64).contiguous()
+            yv = (y if _is_torch(y) else torch.as_tensor(np.asarray(y))).to(device=x.device, dtype=torch.float64).reshape(-1).contiguous()
+            xq = x if x_query is None else x_query.to(device=x.device, dtype=torch.float64).contiguous()
+            if x.dim() != 2 or xq.dim() != 2 or xq.shape[1] != x.shape[1] or yv.numel() != x.shape[0]:
+                raise ValueError("x_mat (n, k), y (n,), x_query (n_q, k) expected")
+            g = torch.empty((xq.shape[0], x.shape[1]), dtype=torch.float64, device=x.device)
+            torch.cuda.current_stream(x.device).synchronize()
+            L.check(self._lib.corrla_grad_mat_dev_f64(self._h, x.data_ptr(), x.shape[0], x.shape[1], yv.data_ptr(), xq.data_ptr(),
+                                                      xq.shape[0], est_order, n_nbrs, float(scale), g.data_ptr(), x.shape[1],
+                                                      C.byref(nreg)))
+            return g.t(), nreg.value
+        x = np.ascontiguousarray(np.asarray(x_mat, dtype=np.float64))
+        yv = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        xq = x if x_query is None else np.ascontiguousarray(np.asarray(x_query, dtype=np.float64))
+        if x.ndim != 2 or xq.ndim != 2 or xq.shape[1] != x.shape[1] or yv.size != x.shape[0]:
+            raise ValueError("x_mat (n, k), y (n,), x_query (n_q, k) expected")
+        g = np.empty((xq.shape[0], x.shape[1]), dtype=np.float64)
+        L.check(self._lib.corrla_grad_mat_f64(self._h, x.ctypes.data, x.shape[0], x.shape[1], yv.ctypes.data, xq.ctypes.data,
+                                              xq.shape[0], est_order, n_nbrs, float(scale), g.ctypes.data, x.shape[1],
+                                              C.byref(nreg)))
+        return g.T, nreg.value
+
     # ---- power_iter ----------------------------------------------------------------------
     def power_iter(self, a_mat, omega_rank, n_iter, *, seed=None, omega=None):
         a = np.asarray(a_mat)

@@ -6,13 +6,15 @@ reference also does after its random_svd calls (k = n_modes, a few tens), writte
   active_ss_fit_svd(grad_mat, n_comps, ...)   <- ActiveSsRsvd::fit_svd   src/lib_math_utils/active_subspaces.rs:233-250
   DMDc(x, u, dt, n_modes, n_iters)            <- DMDc::new               src/lib_math_utils/dmd_rom.rs:45-226
                                                  (pyo3 PyDMDc, src/lib_math_utils_py.rs:222-283)
-Not built here: the kd-tree / local-regression gradient stage of active subspaces, PodI's weights
-and RBF interpolation (out of scope)."""
+  PolyGradientEstimator / ActiveSsRsvd / FittedActiveSsRsvd
+                                              <- src/lib_math_utils/active_subspaces.rs:21-277 (the
+                                                 neighbour search and the local fits run on the GPU)
+Not built here: PodI's weights and RBF interpolation (out of scope)."""
 import numpy as np
 
-from .api import default_context
+from .api import default_context, rsvd
 
-__all__ = ["pod_modes", "active_ss_fit_svd", "DMDc"]
+__all__ = ["pod_modes", "active_ss_fit_svd", "DMDc", "PolyGradientEstimator", "ActiveSsRsvd", "FittedActiveSsRsvd"]
 
 
 def pod_modes(x_data, n_modes, *, seed=None, omega=None, ctx=None):
@@ -29,6 +31,79 @@ def active_ss_fit_svd(grad_mat, n_comps, n_iter=8, n_oversamples=10, *, seed=Non
     u, s, _vt = (ctx or default_context()).rsvd(g * (1.0 / np.sqrt(float(n_samples))), min(k_features, n_comps), n_iter,
                                                 n_oversamples, seed=seed, omega=omega)
     return u, np.diag(s.ravel())
+
+
+class PolyGradientEstimator:
+    """Mirror of ``PolyGradientEstimator`` (active_subspaces.rs:21-141): local polynomial gradient estimates over a
+    point cloud.  The nearest-neighbour search and the per-point least-squares fits run on the GPU
+    (``corrla_grad_mat_f64``); ``grad_at`` returns the reference's 1 x k row."""
+
+    def __init__(self, x_mat, y, est_order, n_nbrs, *, ctx=None):
+        self.x_mat = np.ascontiguousarray(np.asarray(x_mat, dtype=np.float64))
+        self.y = np.asarray(y, dtype=np.float64).reshape(-1)
+        self.est_order, self.n_nbrs, self.k = int(est_order), int(n_nbrs), self.x_mat.shape[1]
+        self._ctx = ctx
+        if self.est_order not in (1, 2):
+            raise ValueError("Not implemented est order")   # the reference panics (active_subspaces.rs:60)
+
+    def grad_mat(self, x_query=None, scale=1.0):
+        """k x n_q gradient matrix (create_grad_mat, active_subspaces.rs:215-229)."""
+        g, self.n_regularised = (self._ctx or default_context()).grad_mat(self.x_mat, self.y, self.est_order, self.n_nbrs,
+                                                                           x_query, scale=scale)
+        return g
+
+    def grad_at(self, x0):
+        return self.grad_mat(np.asarray(x0, dtype=np.float64).reshape(1, -1)).T.copy()
+
+
+class FittedActiveSsRsvd:
+    """active_subspaces.rs:41-47, 143-201."""
+
+    def __init__(self, components, singular_vals, n_comps):
+        self.components_, self.singular_vals_, self.n_comps = components, singular_vals, int(n_comps)
+
+    def components(self):
+        return self.components_[:, : self.n_comps]
+
+    def singular_vals(self):
+        return self.singular_vals_[:, : self.n_comps]
+
+    def transform(self, x_mat):
+        return np.asarray(x_mat, dtype=np.float64) @ self.components()
+
+    def inv_transform(self, x_mat):
+        x = np.asarray(x_mat, dtype=np.float64)
+        if x.shape[1] != self.n_comps:
+            raise ValueError("x_mat must have n_comps columns")     # assert at active_subspaces.rs:186
+        return x @ self.components().T
+
+    def var_diag_evd_sensi(self):
+        m = self.components_.T @ self.singular_vals_ @ self.components_   # as written at active_subspaces.rs:162-164
+        return np.diag(m).copy()
+
+
+class ActiveSsRsvd:
+    """Mirror of ``ActiveSsRsvd`` (active_subspaces.rs:35-277): gradient matrix on the GPU, then either the RSVD of
+    G / sqrt(N) (``fit_svd``, on the GPU) or the eigendecomposition of the k x k matrix G G^T / N (``fit``; the Gram
+    product runs on the GPU through the RSVD library's GEMM, the k x k symmetric eigenproblem in numpy)."""
+
+    def __init__(self, grad_est, n_comps, *, ctx=None):
+        self.grad_est, self.n_comps, self._ctx = grad_est, int(n_comps), ctx
+
+    def fit_svd(self, x_mat, n_iter=None, n_oversamples=None, *, seed=None, omega=None):
+        x = np.asarray(x_mat, dtype=np.float64)
+        g = self.grad_est.grad_mat(x, scale=1.0 / np.sqrt(float(x.shape[0])))       # :238-239
+        u, s, _vt = rsvd(g, min(x.shape[1], self.n_comps), 8 if n_iter is None else n_iter,
+                         10 if n_oversamples is None else n_oversamples, seed=seed, omega=omega, ctx=self._ctx)   # :242-244
+        return FittedActiveSsRsvd(u, np.diag(s.ravel()), self.n_comps)
+
+    def fit(self, x_mat):
+        x = np.asarray(x_mat, dtype=np.float64)
+        g = self.grad_est.grad_mat(x)
+        c = (g @ g.T) * (1.0 / x.shape[0])                                           # :256
+        w, v = np.linalg.eigh(c)
+        order = np.argsort(-w, kind="stable")                                        # sort_evd, mat_utils.rs:459-478
+        return FittedActiveSsRsvd(v[:, order], np.diag(w[order]), self.n_comps)
 
 
 def _pinv_diag(d):  # mat_pinv_diag, mat_utils.rs:386-402

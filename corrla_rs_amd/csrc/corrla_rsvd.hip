@@ -2,9 +2,11 @@
 // is the product: it contains no CPU compute path; without a gfx950 device every compute entry
 // point returns CORRLA_ENODEV / CORRLA_EHIP.
 #include <mutex>
+#include <vector>
 
 #include "capi_impl.hpp"
 #include "hip_backend.hpp"
+#include "grad_kernels.hpp"
 
 using namespace corrla;
 
@@ -192,6 +194,90 @@ CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings*
 
 CORRLA_DEFINE(f32, float)
 CORRLA_DEFINE(f64, double)
+
+// ---- active-subspace gradient stage ------------------------------------------------------
+static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x, int64_t n_pts, int64_t kf, const double* y,
+                                const double* xq, int64_t n_q, int est_order, int64_t n_nbrs, double out_scale, double* g,
+                                int64_t ldg, int* n_regularised) {
+  return guarded([&] {
+    corrla_ctx* c = need(ctx);
+    if (!x || !y || !xq || !g) throw Error(ST_EINVAL, "NULL argument");
+    if (n_pts < 1 || n_q < 1 || kf < 1) throw Error(ST_EINVAL, "empty point set");
+    if (est_order != 1 && est_order != 2) throw Error(ST_EINVAL, "est_order must be 1 or 2 (the reference panics otherwise)");
+    if (kf > k::kGradMaxDim) throw Error(ST_EINVAL, "more than 64 features are not supported");
+    const int64_t need_pts = est_order == 1 ? kf + 1 : kf * (kf + 3) / 2;  // active_subspaces.rs:118-119, 129-130
+    if (!(n_pts > need_pts && n_nbrs > need_pts))
+      throw Error(ST_EINVAL, "n_pts and n_nbrs must exceed k + 1 (order 1) / k (k + 3) / 2 (order 2)");
+    if (n_nbrs > n_pts) throw Error(ST_EINVAL, "n_nbrs exceeds the number of support points");
+    if (n_nbrs > k::kGradMaxNbr) throw Error(ST_EINVAL, "more than 160 neighbours are not supported");
+    const int P = est_order == 1 ? (int)kf + 1 : (int)(kf + kf * (kf + 1) / 2);
+    if (P > k::kGradMaxCols) throw Error(ST_EINVAL, "the design matrix would have more than 65 columns (order 2 needs k <= 9)");
+    if (ldg < kf) throw Error(ST_EINVAL, "ldg < k");
+    if (n_pts > 0x7fffffff || n_q * n_nbrs > ((int64_t)1 << 40)) throw Error(ST_EINVAL, "point set too large");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HipDev& dev = c->dev;
+    dev.begin_call();
+    const int kk = (int)kf, nn = (int)n_nbrs;
+    const double* xd = x;
+    const double* yd = y;
+    const double* qd = xq;
+    double* gd = g;
+    if (host_ptrs) {
+      double* xb = (double*)dev.alloc_bytes(sizeof(double) * (size_t)n_pts * kf);
+      double* yb = (double*)dev.alloc_bytes(sizeof(double) * (size_t)n_pts);
+      double* qb = (double*)dev.alloc_bytes(sizeof(double) * (size_t)n_q * kf);
+      CORRLA_HIP(hipMemcpyAsync(xb, x, sizeof(double) * (size_t)n_pts * kf, hipMemcpyHostToDevice, dev.stream));
+      CORRLA_HIP(hipMemcpyAsync(yb, y, sizeof(double) * (size_t)n_pts, hipMemcpyHostToDevice, dev.stream));
+      CORRLA_HIP(hipMemcpyAsync(qb, xq, sizeof(double) * (size_t)n_q * kf, hipMemcpyHostToDevice, dev.stream));
+      xd = xb;
+      yd = yb;
+      qd = qb;
+      gd = (double*)dev.alloc_bytes(sizeof(double) * (size_t)n_q * kf);
+    }
+    const int64_t ldt = round_up(n_pts, 64);
+    double* xt = (double*)dev.alloc_bytes(sizeof(double) * (size_t)ldt * kf);
+    int* nbr = (int*)dev.alloc_bytes(sizeof(int) * (size_t)n_q * nn);
+    int* status = (int*)dev.alloc_bytes(sizeof(int) * (size_t)n_q);
+    hipLaunchKernelGGL(k::grad_transpose_kernel, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, dev.stream, xd, n_pts, kk, xt,
+                       ldt);
+    const size_t lds_knn = k::knn_lds_bytes(kk, nn), lds_fit = k::grad_fit_lds_bytes(kk, nn, est_order);
+    static bool attrs = false;
+    if (!attrs) {
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::grad_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attrs = true;
+    }
+    if (lds_knn > (size_t)160 * 1024 || lds_fit > (size_t)160 * 1024) throw Error(ST_EINVAL, "problem does not fit in LDS");
+    const int64_t knn_blocks = (n_q + k::kKnnQueries - 1) / k::kKnnQueries;
+    if (knn_blocks > 0x7fffffff || n_q > 0x7fffffff) throw Error(ST_EINVAL, "too many query points for one launch");
+    hipLaunchKernelGGL(k::knn_kernel, dim3((unsigned)knn_blocks), dim3(64 * k::kKnnWaves), lds_knn, dev.stream, (const double*)xt, ldt,
+                       n_pts, kk, qd, n_q, nn, nbr);
+    const int64_t ldgd = host_ptrs ? kf : ldg;
+    hipLaunchKernelGGL(k::grad_fit_kernel, dim3((unsigned)n_q), dim3(64), lds_fit, dev.stream, xd, yd, kk, qd, n_q, (const int*)nbr,
+                       nn, est_order, out_scale, gd, ldgd, status);
+    CORRLA_HIP(hipGetLastError());
+    // how many queries needed the ridge / failed: a short reduction on the host (n_q ints)
+    std::vector<int> hs((size_t)n_q);
+    CORRLA_HIP(hipMemcpyAsync(hs.data(), status, sizeof(int) * (size_t)n_q, hipMemcpyDeviceToHost, dev.stream));
+    if (host_ptrs)
+      CORRLA_HIP(hipMemcpy2DAsync(g, sizeof(double) * (size_t)ldg, gd, sizeof(double) * (size_t)kf, sizeof(double) * (size_t)kf,
+                                  (size_t)n_q, hipMemcpyDeviceToHost, dev.stream));
+    dev.end_call();
+    int bad = 0;
+    for (int v : hs) bad += v != 0;
+    if (n_regularised) *n_regularised = bad;
+  });
+}
+CORRLA_API corrla_status corrla_grad_mat_f64(corrla_ctx* ctx, const double* x, int64_t n_pts, int64_t k, const double* y,
+                                             const double* xq, int64_t n_q, int est_order, int64_t n_nbrs, double out_scale,
+                                             double* g, int64_t ldg, int* n_regularised) {
+  return grad_mat_c(ctx, true, x, n_pts, k, y, xq, n_q, est_order, n_nbrs, out_scale, g, ldg, n_regularised);
+}
+CORRLA_API corrla_status corrla_grad_mat_dev_f64(corrla_ctx* ctx, const double* x, int64_t n_pts, int64_t k, const double* y,
+                                                 const double* xq, int64_t n_q, int est_order, int64_t n_nbrs,
+                                                 double out_scale, double* g, int64_t ldg, int* n_regularised) {
+  return grad_mat_c(ctx, false, x, n_pts, k, y, xq, n_q, est_order, n_nbrs, out_scale, g, ldg, n_regularised);
+}
 
 CORRLA_API corrla_status corrla_comm_unique_id(void* out128) {
   return guarded([&] {

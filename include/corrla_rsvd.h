@@ -205,6 +205,28 @@ CORRLA_API corrla_status corrla_fill_normal_dev_f32(corrla_ctx* ctx, float* p, i
 CORRLA_API corrla_status corrla_fill_normal_dev_f64(corrla_ctx* ctx, double* p, int64_t rows, int64_t cols, int64_t row_stride,
                                          int64_t col_stride, uint64_t seed, int64_t row0, int64_t global_cols);
 
+/* ---- active-subspace gradient stage --------------------------------
+ * Replaces  PolyGradientEstimator::new / grad_at            src/lib_math_utils/active_subspaces.rs:66-141
+ *           ActiveSsRsvd::create_grad_mat                    src/lib_math_utils/active_subspaces.rs:215-229
+ *           (linear_fit / quad_fit / jac_from_lin / jac_from_quad, src/lib_math_utils/stats_corr.rs:146-249)
+ * x  : n_pts x k support points, row-major contiguous (ld = k); y: n_pts values of the scalar function;
+ * xq : n_q x k query points (the reference uses the support points themselves);
+ * est_order 1: least-squares hyper-plane through the n_nbrs nearest support points of each query (needs n_pts,
+ *              n_nbrs > k + 1); 2: quadratic x, x_a x_b (a <= b) WITHOUT a constant term, exactly build_vandermonde
+ *              (needs n_pts, n_nbrs > k (k + 3) / 2).  Limits: k <= 64, n_nbrs <= 160, design columns <= 65.
+ * g  : out_scale * gradients in the reference's k x n_q column-major layout: n_q rows of k contiguous values, row
+ *      stride ldg >= k.  fit_svd (active_subspaces.rs:233-250) passes out_scale = 1 / sqrt(n_q) and hands g to
+ *      corrla_rsvd_dev_f64 as the k x n_q matrix (row_stride 1, col_stride ldg).
+ * n_regularised (optional): queries whose normal equations were numerically singular (the reference's pinv returns
+ *      the minimum-norm fit there; this build retries with a 1e-10 relative ridge, and writes a zero gradient if that
+ *      fails too).  Nearest neighbours are exact (brute force); equal distances are ordered by index. */
+CORRLA_API corrla_status corrla_grad_mat_f64(corrla_ctx* ctx, const double* x, int64_t n_pts, int64_t k, const double* y,
+                                             const double* xq, int64_t n_q, int est_order, int64_t n_nbrs, double out_scale,
+                                             double* g, int64_t ldg, int* n_regularised);
+CORRLA_API corrla_status corrla_grad_mat_dev_f64(corrla_ctx* ctx, const double* x, int64_t n_pts, int64_t k, const double* y,
+                                                 const double* xq, int64_t n_q, int est_order, int64_t n_nbrs,
+                                                 double out_scale, double* g, int64_t ldg, int* n_regularised);
+
 /* ---- measurement hook ---------------------------------------------------------------
  * Times `reps` back-to-back launches of the sketch GEMM Y = A * X (random_svd.rs:31) with
  * hipEvents recorded on the context's stream (the stream the kernel runs on) and returns the

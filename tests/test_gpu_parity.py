@@ -552,3 +552,89 @@ def test_sign_convention_is_stable_across_svd_paths(ctx, monkeypatch):
     for i in range(g["k"]):
         assert ua[int(np.argmax(np.abs(ua[:, i]))), i] > 0
     assert np.max(np.abs(ua - vt0.T)) < 1e-8
+
+
+# ---- active-subspace gradient stage (active_subspaces.rs:66-141, 215-277) ---------
+def _as_samples(cov, n, seed):
+    from oracle import active_ss_oracle as aso
+    return aso.sample_mv_normal(cov, n, np.random.default_rng(seed))
+
+
+@pytest.mark.parametrize("case", ["lin_k6", "lin_k64", "quad_k2", "quad_k3", "quad_k9"])
+def test_grad_mat_matches_the_oracle(ctx, case):
+    """Exact nearest neighbours + local least-squares fits on the GPU against the numpy restatement: same neighbour
+    sets (ties -> lower index), gradients equal to rounding (order 2: the oracle follows the reference's forward
+    differences with eps = 1e-10, the GPU takes the analytic gradient of the same fitted quadratic)."""
+    from oracle import active_ss_oracle as aso
+    rng = np.random.default_rng(len(case))
+    order = 1 if case.startswith("lin") else 2
+    k = int(case.split("k")[1])
+    n = {"lin_k6": 500, "lin_k64": 900, "quad_k2": 100, "quad_k3": 100, "quad_k9": 700}[case]
+    n_nbrs = {"lin_k6": 12, "lin_k64": 90, "quad_k2": 14, "quad_k3": 14, "quad_k9": 80}[case]
+    x = rng.standard_normal((n, k))
+    w = rng.standard_normal(k)
+    y = np.sin(x @ w * 0.3) + 0.1 * (x ** 2).sum(axis=1)
+    nq = 40
+    g, nreg = ctx.grad_mat(x, y, order, n_nbrs, x[:nq])
+    assert g.shape == (k, nq) and nreg == 0
+    est = aso.PolyGradientEstimator(x, y, order, n_nbrs)
+    go = aso.create_grad_mat(est, x[:nq])
+    scale = np.abs(go).max()
+    assert np.max(np.abs(g - go)) <= (1e-9 if order == 1 else 2e-5) * scale
+    # all queries at once == the support points as queries (create_grad_mat's own use)
+    g_all, _ = ctx.grad_mat(x, y, order, n_nbrs)
+    assert g_all.shape == (k, n) and np.array_equal(g_all[:, :nq], g)
+
+
+def test_reference_active_subspace_tests_on_gpu(ctx):
+    """test_grad_est and test_active_ss (active_subspaces.rs:286-394) through the GPU gradient stage and the GPU RSVD."""
+    import corrla_rs_amd as cr
+    from oracle import active_ss_oracle as aso
+    x = _as_samples([[0.9, 0.5], [0.5, 0.9]], 100, 20241008)
+    y = x[:, 0] ** 2 + x[:, 1] ** 2
+    est = cr.PolyGradientEstimator(x, y, 2, 14, ctx=ctx)
+    assert np.allclose(est.grad_at([0.0, 0.0]), [[0.0, 0.0]], atol=1e-2)
+    g1, g2 = est.grad_at([1.0, 0.0]), est.grad_at([-1.0, 0.0])
+    assert g1.shape == (1, 2) and np.allclose(g1, [[2.0, 0.0]], atol=1e-2) and np.allclose(g1, -g2, atol=1e-2)
+
+    x = _as_samples([[0.9, 0.5, 0.5], [0.5, 0.9, 0.5], [0.5, 0.5, 0.9]], 100, 7)
+    y = 0.2 * x[:, 0] + 0.5 * x[:, 1] ** 2 + 0.10 * x[:, 2] * x[:, 0]
+    est = cr.PolyGradientEstimator(x, y, 2, 14, ctx=ctx)
+    act = cr.ActiveSsRsvd(est, 2, ctx=ctx)
+    fit = act.fit(x)
+    assert abs(fit.components()[0, 0]) < abs(fit.components()[1, 0])
+    assert fit.singular_vals()[0, 0] > fit.singular_vals()[1, 1]
+    assert np.allclose(est.grad_at([0.0, 1.0, 0.0]), [[0.2, 1.0, 0.0]], atol=1e-1)
+    tr = fit.transform(x)
+    assert tr.shape == (100, 2) and fit.inv_transform(tr).shape == (100, 3)
+    sens = fit.var_diag_evd_sensi()
+    assert sens.shape == (3,) and sens[1] > sens[0] and sens[1] > sens[2]
+    # fit_svd (no reference test): equals the oracle with the same Omega
+    om = np.random.default_rng(1).standard_normal((3, 3))
+    fs = act.fit_svd(x, omega=om)
+    uo, so = aso.fit_svd(aso.PolyGradientEstimator(x, y, 2, 14), x, 2, omega=om)
+    assert np.allclose(np.diag(fs.singular_vals_), np.diag(so), rtol=1e-6)
+    assert np.linalg.norm(fs.components_ @ fs.components_.T - uo @ uo.T) < 1e-6
+
+
+def test_grad_mat_argument_checks(ctx):
+    x = np.random.default_rng(0).standard_normal((50, 4))
+    y = x.sum(axis=1)
+    for bad in (dict(est_order=3, n_nbrs=10), dict(est_order=1, n_nbrs=5), dict(est_order=2, n_nbrs=14),
+                dict(est_order=1, n_nbrs=60), dict(est_order=1, n_nbrs=200)):
+        with pytest.raises(ValueError):
+            ctx.grad_mat(x, y, bad["est_order"], bad["n_nbrs"])
+
+
+def test_grad_mat_device_tensors_and_duplicate_points(ctx, torch):
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((4000, 16), dtype=torch.float64, device="cuda", generator=g)
+    w = torch.arange(1.0, 17.0, dtype=torch.float64, device="cuda")
+    y = x @ w + 2.0
+    gm, nreg = ctx.grad_mat(x, y, 1, 40)
+    assert gm.is_cuda and gm.shape == (16, 4000) and nreg == 0
+    assert torch.allclose(gm, w.reshape(-1, 1).expand(16, 4000), atol=1e-8)     # affine function: exact slopes
+    # a degenerate cloud (every point repeated): the neighbour set of a query collapses onto few distinct points
+    xd = x[:40].repeat_interleave(25, dim=0)
+    gd, nreg = ctx.grad_mat(xd, xd @ w, 1, 20)
+    assert nreg > 0 and torch.isfinite(gd).all()
