@@ -240,18 +240,40 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     int* status = (int*)dev.alloc_bytes(sizeof(int) * (size_t)n_q);
     hipLaunchKernelGGL(k::grad_transpose_kernel, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, dev.stream, xd, n_pts, kk, xt,
                        ldt);
-    const size_t lds_knn = k::knn_lds_bytes(kk, nn), lds_fit = k::grad_fit_lds_bytes(kk, nn, est_order);
+    const size_t lds_fit = k::grad_fit_lds_bytes(kk, nn, est_order);
     static bool attrs = false;
     if (!attrs) {
       CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       CORRLA_HIP(hipFuncSetAttribute((const void*)k::grad_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attrs = true;
     }
-    if (lds_knn > (size_t)160 * 1024 || lds_fit > (size_t)160 * 1024) throw Error(ST_EINVAL, "problem does not fit in LDS");
-    const int64_t knn_blocks = (n_q + k::kKnnQueries - 1) / k::kKnnQueries;
-    if (knn_blocks > 0x7fffffff || n_q > 0x7fffffff) throw Error(ST_EINVAL, "too many query points for one launch");
-    hipLaunchKernelGGL(k::knn_kernel, dim3((unsigned)knn_blocks), dim3(64 * k::kKnnWaves), lds_knn, dev.stream, (const double*)xt, ldt,
-                       n_pts, kk, qd, n_q, nn, nbr);
+    if (lds_fit > (size_t)160 * 1024) throw Error(ST_EINVAL, "problem does not fit in LDS");
+    if (n_q > 0x7fffffff) throw Error(ST_EINVAL, "too many query points for one launch");
+    // Both kernels spend ~n_nbrs ln(n_pts / n_nbrs) list insertions per query; the MFMA distance tile only pays off
+    // once the scan itself dominates (measured cross-over between 1e5 and 1e6 support points)
+    const int knn_mode = env_int("CORRLA_KNN", 0);  // 1: VALU kernel, 2: MFMA kernel, 0: by size
+    if (knn_mode == 1 || (knn_mode == 0 && n_pts < 262144)) {
+      const size_t lds_knn = k::knn_lds_bytes(kk, nn);
+      const int64_t knn_blocks = (n_q + k::kKnnQueries - 1) / k::kKnnQueries;
+      hipLaunchKernelGGL(k::knn_kernel, dim3((unsigned)knn_blocks), dim3(64 * k::kKnnWaves), lds_knn, dev.stream, (const double*)xt,
+                         ldt, n_pts, kk, qd, n_q, nn, nbr);
+    } else {
+      double* pnorm = (double*)dev.alloc_bytes(sizeof(double) * (size_t)n_pts);
+      hipLaunchKernelGGL(k::point_norms_kernel, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, dev.stream, (const double*)xt, ldt,
+                         n_pts, kk, pnorm);
+      const int waves = k::knn_mfma_lds_bytes(kk, nn, 4) <= (size_t)160 * 1024 ? 4 : 2;
+      const size_t lds_knn = k::knn_mfma_lds_bytes(kk, nn, waves);
+      if (lds_knn > (size_t)160 * 1024) throw Error(ST_EINVAL, "problem does not fit in LDS");
+      const int64_t knn_blocks = (n_q + 16 * waves - 1) / (16 * waves);
+      if (waves == 4)
+        hipLaunchKernelGGL(k::knn_mfma_kernel<4>, dim3((unsigned)knn_blocks), dim3(256), lds_knn, dev.stream, (const double*)xt, ldt,
+                           (const double*)pnorm, n_pts, kk, qd, n_q, nn, nbr);
+      else
+        hipLaunchKernelGGL(k::knn_mfma_kernel<2>, dim3((unsigned)knn_blocks), dim3(128), lds_knn, dev.stream, (const double*)xt, ldt,
+                           (const double*)pnorm, n_pts, kk, qd, n_q, nn, nbr);
+    }
     const int64_t ldgd = host_ptrs ? kf : ldg;
     hipLaunchKernelGGL(k::grad_fit_kernel, dim3((unsigned)n_q), dim3(64), lds_fit, dev.stream, xd, yd, kk, qd, n_q, (const int*)nbr,
                        nn, est_order, out_scale, gd, ldgd, status);

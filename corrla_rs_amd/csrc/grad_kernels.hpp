@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace corrla {
 namespace k {
@@ -126,6 +127,239 @@ inline size_t knn_lds_bytes(int k, int n_nbrs) {
   return (size_t)k * 64 * 8 + (size_t)kKnnQueries * k * 8 + (size_t)kKnnQueries * n_nbrs * 12 + 64;
 }
 
+// ---- k-NN with the distance tile on the f64 MFMA ---------------------------------------------------------
+// d^2(q, p) = |q|^2 + |p|^2 - 2 q.p: each wave owns 16 queries whose MFMA A-fragments (16 x 4 slices of the query
+// block) stay in registers for the whole scan; per chunk of 64 points it issues 4 x k/4 v_mfma_f64_16x16x4_f64 against
+// the LDS-staged points (row pitch 80 doubles: the two dimension rows of a 32-lane ds_read_b64 pass fall in different
+// bank halves).  The MFMA value is only a FILTER (margin 1e-12 (|q|^2 + |p|^2)); a candidate that passes gets its exact
+// distance sum_d (p_d - q_d)^2 recomputed across the lanes before it may enter the sorted list, so the neighbour sets
+// and their order are those of the exact search.
+typedef double knn_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kKnnPitch = 80;
+__device__ __forceinline__ double wave_max_f64(double x) {
+  auto dpp = [](double v, auto ctrl) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, decltype(ctrl)::value, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, decltype(ctrl)::value, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  x = fmax(x, dpp(x, std::integral_constant<int, 0xB1>{}));
+  x = fmax(x, dpp(x, std::integral_constant<int, 0x4E>{}));
+  x = fmax(x, dpp(x, std::integral_constant<int, 0x141>{}));
+  x = fmax(x, dpp(x, std::integral_constant<int, 0x140>{}));
+  x = fmax(x, __shfl_xor(x, 16, 64));
+  x = fmax(x, __shfl_xor(x, 32, 64));
+  return x;
+}
+// sum over the 64 lanes, result in every lane: DPP inside the 16-lane rows, two cross-row exchanges
+__device__ __forceinline__ double wave_sum_f64(double x) {
+  auto dpp = [](double v, auto ctrl) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, decltype(ctrl)::value, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, decltype(ctrl)::value, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  x += dpp(x, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+  x += dpp(x, std::integral_constant<int, 0x141>{});  // row_half_mirror
+  x += dpp(x, std::integral_constant<int, 0x140>{});  // row_mirror
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+template <int W>
+__global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restrict__ xt, int64_t ldt,
+                                                          const double* __restrict__ pnorm, int64_t n_pts, int k,
+                                                          const double* __restrict__ xq, int64_t n_q, int n_nbrs,
+                                                          int* __restrict__ nbr) {
+  constexpr int QT = 16 * W;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int k4 = (k + 3) & ~3, nks = k4 >> 2;
+  double* qv = (double*)smem;                       // [QT][k4]
+  double* qn = qv + (size_t)QT * k4;                // [QT]
+  double* pts = qn + QT;                            // [k4][kKnnPitch]
+  double* pn = pts + (size_t)k4 * kKnnPitch;        // [64]
+  double* ld = pn + 64;                             // [QT][n_nbrs]
+  int* li = (int*)(ld + (size_t)QT * n_nbrs);       // [QT][n_nbrs]
+  double* qmax = (double*)(li + (size_t)QT * n_nbrs + ((QT * n_nbrs) & 1));  // [QT] current n-th distance
+  int* qmaxpos = (int*)(qmax + QT);                 // [QT] its slot in the (unsorted) list
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t q0 = (int64_t)blockIdx.x * QT;
+  for (int idx = tid; idx < QT * k4; idx += blockDim.x) {
+    const int qq = idx / k4, d = idx - qq * k4;
+    qv[idx] = (q0 + qq < n_q && d < k) ? xq[(q0 + qq) * k + d] : 0.0;
+  }
+  for (int idx = tid; idx < QT * n_nbrs; idx += blockDim.x) {
+    ld[idx] = __builtin_huge_val();
+    li[idx] = -1;
+  }
+  if (tid < QT) {
+    qmax[tid] = __builtin_huge_val();
+    qmaxpos[tid] = n_nbrs - 1;
+  }
+  __syncthreads();
+  if (tid < QT) {
+    double s = 0.0;
+    for (int d = 0; d < k4; ++d) s += qv[tid * k4 + d] * qv[tid * k4 + d];
+    qn[tid] = s;
+  }
+  __syncthreads();
+  // A fragments of this wave's 16 queries: lane (i = lane & 15, kk = lane >> 4) holds Q[i][4 ks + kk]
+  double afr[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) afr[ks] = ks < nks ? qv[(wave * 16 + (lane & 15)) * k4 + 4 * ks + (lane >> 4)] : 0.0;
+  // D layout: column (point) = lane & 15, row (query) = (lane >> 4) + 4 r
+  double qn_r[4], tau_r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    qn_r[r] = qn[wave * 16 + (lane >> 4) + 4 * r];
+    tau_r[r] = __builtin_huge_val();
+  }
+  const int64_t nchunks = (n_pts + 63) / 64;
+  // the next chunk of points travels global -> registers while the MFMAs work on the current one
+  constexpr int PER = 64 / W;  // (64 dims x 64 points) / (64 W threads)
+  double pre[PER];
+  double pre_n = 0.0;
+  auto fetch = [&](int64_t cc) {
+    const int64_t b2 = cc * 64;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + i * 64 * W;
+      const int d = idx >> 6, j = idx & 63;
+      pre[i] = (d < k && b2 + j < n_pts) ? xt[(int64_t)d * ldt + b2 + j] : 0.0;
+    }
+    if (tid < 64) pre_n = b2 + tid < n_pts ? pnorm[b2 + tid] : 0.0;
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + i * 64 * W;
+      const int d = idx >> 6, j = idx & 63;
+      if (d < k4) pts[d * kKnnPitch + j] = pre[i];
+    }
+    if (tid < 64) pn[tid] = pre_n;
+  };
+  if (nchunks > 0) fetch(0);
+  for (int64_t c = 0; c < nchunks; ++c) {
+    __syncthreads();  // everyone is done with the previous chunk
+    const int64_t base = c * 64;
+    stash();
+    __syncthreads();
+    if (c + 1 < nchunks) fetch(c + 1);
+    knn_f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (knn_f64x4){0, 0, 0, 0};
+    const double* bp = pts + (lane >> 4) * kKnnPitch + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks < nks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], bp[(4 * ks) * kKnnPitch + 16 * t], acc[t], 0, 0, 0);
+      }
+    }
+    unsigned hits = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pl = 16 * t + (lane & 15);
+      const double pnv = pn[pl];
+      const bool pvalid = base + pl < n_pts;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double nsum = qn_r[r] + pnv;
+        const double dm = nsum - 2.0 * acc[t][r];
+        if (pvalid && dm - 1e-12 * nsum < tau_r[r]) hits |= 1u << (4 * t + r);
+      }
+    }
+    if (__any(hits != 0)) {
+      // slow path (rare once the lists have warmed up).  Point tile t outer, lanes ascending: the candidates of one
+      // query arrive in increasing point index, so equal distances keep the lower index first.
+#pragma unroll 1
+      for (int t = 0; t < 4; ++t) {
+        unsigned long long mask = __ballot(((hits >> (4 * t)) & 0xFu) != 0);
+        while (mask) {
+          const int b = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          unsigned rb = ((unsigned)__shfl((int)hits, b, 64) >> (4 * t)) & 0xFu;
+          const int pl = 16 * t + (b & 15);
+          while (rb) {
+            const int r = __ffs((int)rb) - 1;
+            rb &= rb - 1;
+            const int qq = wave * 16 + (b >> 4) + 4 * r;
+            if (q0 + qq >= n_q) continue;  // padding query rows
+            double df = 0.0;
+            if (lane < k) df = pts[lane * kKnnPitch + pl] - qv[qq * k4 + lane];
+            const double cd = wave_sum_f64(df * df);
+            double* qd = ld + (size_t)qq * n_nbrs;
+            int* qix = li + (size_t)qq * n_nbrs;
+            if (!(cd < qmax[qq])) continue;  // equal distance: the earlier (lower) index stays
+            // unsorted list: the candidate replaces the current n-th entry, then the new maximum is located
+            // (largest distance, among equal ones the largest index)
+            const int slot = qmaxpos[qq];
+            if (lane == 0) {
+              qd[slot] = cd;
+              qix[slot] = (int)(base + pl);
+            }
+            __builtin_amdgcn_wave_barrier();
+            double mv = -1.0;
+            int mi = -2, mp = 0;
+            for (int e = lane; e < n_nbrs; e += 64) {
+              const double v = qd[e];
+              const int ix = qix[e];
+              if (v > mv || (v == mv && ix > mi)) {
+                mv = v;
+                mi = ix;
+                mp = e;
+              }
+            }
+            const double wmax = wave_max_f64(mv);
+            unsigned long long who = __ballot(mv == wmax);
+            if (__popcll(who) > 1) {  // several lanes hold the maximum value (duplicates, empty slots): largest index
+              int wi = (mv == wmax) ? mi : -2;
+              for (int off = 32; off > 0; off >>= 1) wi = max(wi, __shfl_xor(wi, off, 64));
+              who = __ballot(mv == wmax && mi == wi);
+            }
+            const int wl = __ffsll((long long)who) - 1;
+            const int wp = __shfl(mp, wl, 64);
+            if (lane == 0) {
+              qmax[qq] = wmax;
+              qmaxpos[qq] = wp;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tau_r[r] = qmax[wave * 16 + (lane >> 4) + 4 * r];
+    }
+  }
+  __syncthreads();
+  // nearest first, equal distances by index: rank of every entry inside its list
+  for (int idx = tid; idx < QT * n_nbrs; idx += blockDim.x) {
+    const int qq = idx / n_nbrs, e = idx - qq * n_nbrs;
+    if (q0 + qq >= n_q) continue;
+    const double* qd = ld + (size_t)qq * n_nbrs;
+    const int* qix = li + (size_t)qq * n_nbrs;
+    const double v = qd[e];
+    const int ix = qix[e];
+    int rank = 0;
+    for (int f = 0; f < n_nbrs; ++f) rank += (qd[f] < v || (qd[f] == v && qix[f] < ix)) ? 1 : 0;
+    nbr[(q0 + qq) * n_nbrs + rank] = ix;
+  }
+}
+inline size_t knn_mfma_lds_bytes(int k, int n_nbrs, int waves) {
+  const int k4 = (k + 3) & ~3, qt = 16 * waves;
+  return ((size_t)qt * k4 + qt + (size_t)k4 * kKnnPitch + 64 + (size_t)qt * n_nbrs + qt) * 8 + ((size_t)qt * n_nbrs + 1 + qt) * 4 + 64;
+}
+// |p|^2 of every support point (from the dimension-major copy)
+__global__ void point_norms_kernel(const double* __restrict__ xt, int64_t ldt, int64_t n, int k, double* pn) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int d = 0; d < k; ++d) s += xt[(int64_t)d * ldt + i] * xt[(int64_t)d * ldt + i];
+  pn[i] = s;
+}
+
 // g[q * ldg + m] = out_scale * d(fit)/dx_m at query q.  status[q]: 0 ok, 1 ridge-regularised (rank-deficient design).
 __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__ x, const double* __restrict__ y, int k,
                                                       const double* __restrict__ xq, int64_t n_q,
@@ -207,7 +441,7 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
       // row j of L: L(j, c) for c < j is final; pivot
       double s = 0.0;
       for (int c = lane; c < j; c += 64) s += M[j * LM + c] * M[j * LM + c];
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      s = wave_sum_f64(s);
       const double piv = M[j * LM + j] + ridge - s;
       if (!(piv > 1e-13 * dmax)) {
         ok = false;
@@ -251,7 +485,7 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
     for (int i = 0; i < P; ++i) {
       double s = 0.0;
       for (int c = lane; c < i; c += 64) s += M[i * LM + c] * beta[c];
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      s = wave_sum_f64(s);
       __syncthreads();
       if (lane == 0) beta[i] = (M[i * LM + P] - s) / M[i * LM + i];
       __syncthreads();
@@ -259,7 +493,7 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
     for (int i = P - 1; i >= 0; --i) {
       double s = 0.0;
       for (int c = i + 1 + lane; c < P; c += 64) s += M[c * LM + i] * beta[c];
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      s = wave_sum_f64(s);
       __syncthreads();
       if (lane == 0) beta[i] = (beta[i] - s) / M[i * LM + i];
       __syncthreads();

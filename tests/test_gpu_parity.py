@@ -617,6 +617,21 @@ def test_reference_active_subspace_tests_on_gpu(ctx):
     assert np.linalg.norm(fs.components_ @ fs.components_.T - uo @ uo.T) < 1e-6
 
 
+def test_knn_kernels_agree(ctx, monkeypatch):
+    """The VALU scan and the MFMA-filtered scan (exact re-check of every candidate) return the same neighbour sets,
+    hence the same gradients, including a cloud with repeated points (equal distances -> lower index)."""
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((3000, 24))
+    x[1000:1500] = x[:500]                      # exact duplicates
+    y = np.cos(x @ rng.standard_normal(24) * 0.2)
+    out = {}
+    for mode in ("1", "2"):
+        monkeypatch.setenv("CORRLA_KNN", mode)
+        out[mode], _ = ctx.grad_mat(x, y, 1, 60, x[:700])
+    monkeypatch.delenv("CORRLA_KNN")
+    assert np.max(np.abs(out["1"] - out["2"])) <= 1e-10 * np.abs(out["1"]).max()
+
+
 def test_grad_mat_argument_checks(ctx):
     x = np.random.default_rng(0).standard_normal((50, 4))
     y = x.sum(axis=1)
