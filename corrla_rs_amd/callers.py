@@ -97,6 +97,29 @@ class ActiveSsRsvd:
                          10 if n_oversamples is None else n_oversamples, seed=seed, omega=omega, ctx=self._ctx)   # :242-244
         return FittedActiveSsRsvd(u, np.diag(s.ravel()), self.n_comps)
 
+    def fit_svd_sharded(self, x_mat, rank, world, n_iter=None, n_oversamples=None, *, seed=1):
+        """``fit_svd`` with the sample points sharded over `world` GPUs, one process per GPU (BASELINE config 5): the
+        support cloud is replicated, rank r estimates the gradients of its contiguous slice of the samples (no
+        exchange), and the RSVD of G / sqrt(N) runs on the row-sharded N x k tall view (``rsvd_sharded``: all-reduces of
+        k x l blocks only).  The context must carry a communicator (``Context.comm_init``).  Every rank returns the
+        same fitted object."""
+        import torch
+        x = np.asarray(x_mat, dtype=np.float64)
+        n = x.shape[0]
+        lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+        ctx = self._ctx or default_context()
+        dev = torch.device(f"cuda:{ctx.device}")
+        xs = torch.as_tensor(np.ascontiguousarray(self.grad_est.x_mat), device=dev)
+        ys = torch.as_tensor(self.grad_est.y, device=dev)
+        g_loc, self.grad_est.n_regularised = ctx.grad_mat(xs, ys, self.grad_est.est_order, self.grad_est.n_nbrs,
+                                                          torch.as_tensor(np.ascontiguousarray(x[lo:hi]), device=dev),
+                                                          scale=1.0 / np.sqrt(float(n)))
+        k_comp = min(x.shape[1], self.n_comps)
+        _u_loc, s, vt = ctx.rsvd_sharded(g_loc.t(), k_comp, 8 if n_iter is None else n_iter,
+                                         10 if n_oversamples is None else n_oversamples, seed=seed)
+        # the tall view is G^T (N x k): its right singular vectors are the k x r components `ur` of fit_svd
+        return FittedActiveSsRsvd(vt.t().cpu().numpy().copy(), np.diag(s.cpu().numpy().ravel()), self.n_comps)
+
     def fit(self, x_mat):
         x = np.asarray(x_mat, dtype=np.float64)
         g = self.grad_est.grad_mat(x)

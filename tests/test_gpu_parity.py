@@ -535,6 +535,25 @@ def test_sharded_entry_point_with_world_size_1_rccl(torch):
     c.close()
 
 
+def test_active_subspace_fit_svd_sharded_world_size_1(torch):
+    """BASELINE config 5's multi-GPU shape (queries sharded, cloud replicated, row-sharded RSVD of G^T) rehearsed with
+    one rank and a real RCCL communicator: same spectrum and subspace as the single-process fit_svd."""
+    import corrla_rs_amd as cr
+    c = cr.Context(0)
+    c.comm_init(cr.Context.unique_id(), 0, 1)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((4000, 12))
+    y = np.sin(x[:, 0] + 0.5 * x[:, 3]) + 0.1 * x[:, 7] ** 2
+    est = cr.PolyGradientEstimator(x, y, 1, 30, ctx=c)
+    act = cr.ActiveSsRsvd(est, 3, ctx=c)
+    f1 = act.fit_svd_sharded(x, 0, 1, seed=5)
+    f0 = act.fit_svd(x, seed=5)
+    assert np.allclose(np.diag(f1.singular_vals_), np.diag(f0.singular_vals_), rtol=1e-9)
+    assert np.linalg.norm(f1.components_ @ f1.components_.T - f0.components_ @ f0.components_.T) < 1e-8
+    assert abs(f0.components_[0, 0]) > 0.5      # the active direction is dominated by x0
+    c.close()
+
+
 def test_sign_convention_is_stable_across_svd_paths(ctx, monkeypatch):
     """Largest-magnitude component of the short-side singular vector is positive, so the LDS, block and host
     SVD paths return the same signs (bitwise-different rounding, identical orientation)."""
