@@ -78,7 +78,7 @@ constexpr int kRowBytes = 256;  // LDS row of the k-contiguous images
 #define CORRLA_PD 4
 #endif
 constexpr int kPrefetchSteps = CORRLA_PD;  // LDS fragment reads run this many MFMA steps ahead
-constexpr int kLoaders = 4;      // LDS-DMA loader waves per workgroup (besides the 4 MFMA waves); 1 or 2
+constexpr int kLoaders = 4;      // LDS-DMA loader waves per workgroup (besides the 4 MFMA waves); must divide 4
 // A workgroup owns 64*MW outer indices (4 waves x MW 16-wide MFMA tiles each).  MW = 2 halves the
 // skinny-operand bytes staged per MFMA (the per-CU global->LDS fill rate, ~11 B/clk, is what bounds
 // the MW = 1 shape at 144 columns: 52 KiB per 4608 MFMA cycles); MW = 1 keeps small problems spread
