@@ -672,3 +672,16 @@ def test_grad_mat_device_tensors_and_duplicate_points(ctx, torch):
     xd = x[:40].repeat_interleave(25, dim=0)
     gd, nreg = ctx.grad_mat(xd, xd @ w, 1, 20)
     assert nreg > 0 and torch.isfinite(gd).all()
+
+
+def test_randomised_parity_sweep(ctx):
+    """tools/fuzz_parity.py: random shapes / dtypes / layouts / ranks / q / p / spectra (flat, decaying, rank-deficient,
+    scaled by 1e-6..1e6) against the oracle with a shared Omega, restricted to sketches the arithmetic can resolve."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, worst = mod.run(150, seed=3, ctx=ctx, verbose=True)
+    assert bad == 0, worst
+    assert worst["ds"] < 1e-8 and worst["relerr"] < 1e-8 and worst["orth"] < 1e-10

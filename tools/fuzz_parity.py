@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the HIP path against the oracle (shared Omega): shapes, dtypes, layouts, ranks, q, p,
+spectra (flat / decaying / rank-deficient / scaled).  Prints the worst deviations; exits non-zero on a violation."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import corrla_rs_amd as cr  # noqa: E402
+from oracle import rsvd_oracle as orc  # noqa: E402
+
+
+
+def run(n_cases=200, seed=0, ctx=None, verbose=True):
+  """Returns (violations, worst f64 deviations)."""
+  rng = np.random.default_rng(seed)
+  ctx = ctx or cr.Context(0)
+  worst = {"ds": 0.0, "relerr": 0.0, "orth": 0.0}
+  bad = 0
+  for case in range(n_cases):
+      m = int(rng.integers(1, 700))
+      n = int(rng.integers(1, 400))
+      dtype = np.float64 if rng.random() < 0.5 else np.float32
+      kind = rng.choice(["flat", "decay", "rankdef", "scaled"])
+      a = rng.standard_normal((m, n))
+      if kind == "decay":
+          a = a * (rng.uniform(0.9, 0.995) ** np.arange(n))
+      elif kind == "rankdef":
+          r = int(rng.integers(1, max(2, min(m, n) // 2 + 1)))
+          a = rng.standard_normal((m, r)) @ rng.standard_normal((r, n))
+      elif kind == "scaled":
+          a = a * 10.0 ** rng.uniform(-6, 6)
+      a = a.astype(dtype)
+      if rng.random() < 0.3:
+          a = np.asfortranarray(a)
+      nt = min(m, n)
+      k = int(rng.integers(1, nt + 1))
+      k = min(k, 160)
+      p = int(rng.integers(0, 12))
+      q = int(rng.integers(0, 7))
+      l = min(k + p, nt)
+      om = rng.standard_normal((nt, l)).astype(dtype)
+      # Only well-posed comparisons: the reference schedule runs its first three power iterations without any
+      # re-orthonormalisation (random_svd.rs:37), so directions with (sigma_l / sigma_1)^(2 min(q,3) + 1) below the
+      # arithmetic's resolution are rounding noise in EVERY implementation (and differ between them).
+      sv = np.linalg.svd(a.astype(np.float64), compute_uv=False)
+      eps = np.finfo(dtype).eps
+      if sv[0] == 0 or kind == "rankdef":
+          pass
+      elif (sv[l - 1] / sv[0]) ** (2 * min(q, 3) + 1) < 1e4 * eps:
+          continue
+      try:
+          u, s, vt = ctx.rsvd(a, k, q, p, omega=om)
+      except Exception as e:  # noqa: BLE001
+          if verbose: print("EXCEPTION", case, (m, n), dtype.__name__, kind, k, q, p, repr(e)[:200])
+          bad += 1
+          continue
+      uo, so, vto = orc.random_svd(a.astype(np.float64), k, q, p, omega=om.astype(np.float64))
+      f64 = dtype == np.float64
+      s1 = max(so[0, 0], 1e-300)
+      ds = float(np.max(np.abs(s.astype(np.float64) - so)) / s1)
+      re = abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto))
+      # orthonormality only over the numerically non-null triplets (null directions are an arbitrary completion)
+      keep = so.ravel() > (1e-9 if f64 else 1e-4) * s1
+      uu = u[:, keep].astype(np.float64)
+      oe = float(np.max(np.abs(uu.T @ uu - np.eye(uu.shape[1])))) if uu.size else 0.0
+      # tolerances: the conditioning of the sketch enters through (s_l / s_1)^(2q+1); compare loosely and report
+      tol_ds = 1e-8 if f64 else 2e-3
+      tol_re = 1e-7 if f64 else 2e-3
+      tol_oe = 1e-8 if f64 else 2e-3
+      worst["ds"] = max(worst["ds"], ds if f64 else 0.0)
+      worst["relerr"] = max(worst["relerr"], re if f64 else 0.0)
+      worst["orth"] = max(worst["orth"], oe if f64 else 0.0)
+      if not (np.all(np.isfinite(s)) and ds <= tol_ds and re <= tol_re and oe <= tol_oe and np.all(np.diff(s.ravel()) <= 1e-6 * s1)):
+          if verbose: print("VIOLATION", case, (m, n), dtype.__name__, kind, "k", k, "q", q, "p", p, "l", l, "ds %.2e re %.2e orth %.2e" % (ds, re, oe))
+          bad += 1
+  return bad, worst
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    bad, worst = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print("cases", n_cases, "violations", bad, "worst f64:", {k_: "%.2e" % v for k_, v in worst.items()})
+    sys.exit(1 if bad else 0)
