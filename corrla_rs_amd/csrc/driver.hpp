@@ -185,6 +185,38 @@ struct RsvdDriver {
 
   int64_t orthonormalize(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough = false) {
     const int64_t l = y.cols;
+    int64_t r = orthonormalize_core(y, tmp, sharded, rough);
+    // A Householder thin-Q (random_svd.rs:38,57) is orthonormal whatever the rank of its input: the directions a
+    // rank-deficient sketch does not determine are an arbitrary orthonormal completion.  Reproduce that instead of
+    // leaving zero columns (in-loop, the completion re-seeds directions the next product with A can pick up again).
+    if (r < l && !defer_status_ && y.rows >= l) r = complete_basis(y, r, sharded);
+    return r;
+  }
+
+  // columns [r, l) of y <- orthonormal vectors orthogonal to the first r columns: Gaussian block, two projection
+  // passes against Q_r, Cholesky-QR of the remainder
+  int64_t complete_basis(Skinny<T>& y, int64_t r, bool sharded) {
+    const int64_t l = y.cols, c = l - r, m = y.rows;
+    Skinny<T> yc = dev.template alloc_skinny<T>(m, c);
+    Skinny<T> pc = dev.template alloc_skinny<T>(m, c);
+    Skinny<T> tc = dev.template alloc_skinny<T>(m, c);
+    dev.fill_normal(yc.p, m, c, (int64_t)1, yc.ld, (uint64_t)(0x9e3779b97f4a7c15ull ^ (uint64_t)(131 * r + l)), (int64_t)0, c);
+    if (r > 0) {
+      for (int pass = 0; pass < 2; ++pass) {
+        Skinny<T> t = dev.template alloc_skinny<T>(r, c);
+        dev.gemm_nn(as_rowmajor_transposed(y, r), yc, t, kNone);  // Q_r^T Yc
+        if (sharded) dev.allreduce(t.p, (size_t)t.ld * (size_t)t.cols_alloc);
+        dev.gemm_tn(as_rowmajor_transposed(y, r), t, pc, kNone);  // Q_r (Q_r^T Yc)
+        dev.sub_inplace(yc, pc);
+      }
+    }
+    const int64_t rc = orthonormalize_core(yc, tc, sharded, false);
+    dev.copy_cols(yc, y, r, rc);
+    return r + rc;
+  }
+
+  int64_t orthonormalize_core(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough) {
+    const int64_t l = y.cols;
     int64_t r = l;
     if (dev.template device_chol_fits<T>(l)) {
       // Optimistic CholeskyQR2 entirely on the device: [Gram, Cholesky + inverse, apply] x2 are enqueued
@@ -352,23 +384,21 @@ struct RsvdDriver {
     a_times(a, om, y, kNone);  // :31
     dev.event_mark(1);
     phase(tm.sketch_ms, pt);
-    const T* scale = nullptr;
     for (int64_t i = 0; i < n_iter; ++i) {  // :35
       if (i > 2) {                          // :37-39
-        if (scale) dev.scale_inplace(y, scale);
         phase(tm.power_ms, pt);
         orthonormalize(y, y2, o.sharded, /*rough=*/true);
         phase(tm.qr_ms, pt);
-        scale = nullptr;
       }
-      at_times(a, y, z, scale, o.sharded);  // :42-46 (the 1/||Y||_F of :53-55 is folded in here)
-      a_times(a, z, y, kNone);            // :47-51
+      at_times(a, y, z, kNone, o.sharded);  // :42-46
+      a_times(a, z, y, kNone);              // :47-51
       dev.sumsq(y, ss_dev);                 // :54 norm_l2 (Frobenius)
       if (o.sharded) dev.allreduce_f64(ss_dev, 1);
       dev.rsqrt_scalar(ss_dev, inv_dev);
-      scale = inv_dev;
+      // :53-55.  Applied to Y itself, like the reference: folding 1/||Y|| into the NEXT product's epilogue would
+      // form A^T Y unscaled first and overflow f32 a factor sigma_1 earlier than the reference does.
+      dev.scale_inplace(y, inv_dev);
     }
-    if (scale) dev.scale_inplace(y, scale);  // :53-55 for the last iteration
     phase(tm.power_ms, pt);
     int64_t r = orthonormalize(y, y2, o.sharded);  // :57
     phase(tm.qr_ms, pt);
@@ -438,6 +468,19 @@ struct RsvdDriver {
     Skinny<T> m1 = dev.template alloc_skinny<T>(l, k);  // U~[:, :k] = Vc[:, :k]
     Skinny<T> m2 = dev.template alloc_skinny<T>(l, k);  // Uc[:, :k]
     dev.small_svd(cd, l, k, m1, m2, s_dev);
+    if (!defer_status_) {
+      // Exactly singular core (rank-deficient or zero input; only reachable through the host-controlled path): the
+      // left vectors w_j / sigma_j of its null triplets do not exist.  Give them an orthonormal completion, like
+      // the arbitrary-but-orthonormal null vectors of the reference's full SVD.
+      std::vector<T> sh((size_t)k);
+      dev.copy_values_out(s_dev, k, sh.data(), /*dst_is_host=*/true);
+      // numerically null: below eps * 1e-3 of the largest singular value nothing of the direction survives the
+      // products that formed the core
+      const T null_tol = (T)(1e-3 * (double)std::numeric_limits<T>::epsilon()) * sh[0];
+      int64_t nz = 0;
+      while (nz < k && sh[(size_t)nz] > null_tol) ++nz;
+      if (nz < k) complete_basis(m2, nz, false);
+    }
     phase(tm.small_svd_ms, pt);
     // U = Q * U~[:, :k]                                                               :92, :96-109
     dev.gemm_tn(as_rowmajor_transposed(q, l), m1, u_tall, kNone);

@@ -286,6 +286,21 @@ class HipDev {
   void copy_skinny(const Skinny<T>& src, Skinny<T>& dst) {
     CORRLA_HIP(hipMemcpyAsync(dst.p, src.p, (size_t)src.ld * src.cols_alloc * sizeof(T), hipMemcpyDeviceToDevice, stream));
   }
+  // dst columns [c0, c0 + n) <- src columns [0, n)  (same row count, hence the same leading dimension)
+  template <class T>
+  void copy_cols(const Skinny<T>& src, Skinny<T>& dst, int64_t c0, int64_t n) {
+    if (src.ld != dst.ld) throw Error(ST_EINVAL, "internal: copy_cols needs equal leading dimensions");
+    if (n > 0)
+      CORRLA_HIP(hipMemcpyAsync(dst.p + c0 * dst.ld, src.p, (size_t)n * src.ld * sizeof(T), hipMemcpyDeviceToDevice, stream));
+  }
+  // y -= p over the whole (padded) allocation
+  template <class T>
+  void sub_inplace(Skinny<T>& y, const Skinny<T>& p) {
+    const int64_t n = y.ld * std::min(y.cols_alloc, p.cols_alloc);
+    const int blocks = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (n + 255) / 256));
+    hipLaunchKernelGGL((k::sub_kernel<T>), dim3(blocks), dim3(256), 0, stream, y.p, (const T*)p.p, n);
+    CORRLA_HIP(hipGetLastError());
+  }
   template <class T>
   void zero_cols(Skinny<T>& s, int64_t c0, int64_t c1) {
     if (c1 > c0) memset_zero(s.p + c0 * s.ld, (size_t)(c1 - c0) * s.ld * sizeof(T));

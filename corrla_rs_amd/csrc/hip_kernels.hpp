@@ -29,6 +29,8 @@
 // of the tile row for BOTH operands.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <limits>
 #include <stdint.h>
 
 #include <type_traits>
@@ -606,6 +608,10 @@ __global__ void rsqrt_scalar_kernel(const double* ss, T* out) {
   *out = (T)(v > 0.0 ? 1.0 / sqrt(v) : 0.0);
 }
 template <class T>
+__global__ void sub_kernel(T* y, const T* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] -= p[i];
+}
+template <class T>
 __global__ void scale_kernel(T* y, int64_t n, const T* scale) {
   const T sc = *scale;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -709,8 +715,8 @@ __device__ __forceinline__ double group_sum(double x) {
 // VALU-issue bound and the IEEE sqrt/div sequences were ~1/4 of their instruction stream); f64 stays IEEE.
 __device__ __forceinline__ bool jacobi_rotation(float a, float b, float g, float tol, float& cs, float& sn, float& rel,
                                                 float& t) {
-  const float ab2 = a * b;
-  const float rs = ab2 > 0.f ? __builtin_amdgcn_rsqf(ab2) : 0.f;
+  // |g| / sqrt(a b) without forming a * b (two tiny columns would underflow it and never be rotated)
+  const float rs = (a > 0.f && b > 0.f) ? __builtin_amdgcn_rsqf(a) * __builtin_amdgcn_rsqf(b) : 0.f;
   rel = fabsf(g) * rs;
   if (!(rel > tol)) return false;
   const float zeta = (b - a) * 0.5f * __builtin_amdgcn_rcpf(g);
@@ -726,7 +732,7 @@ __device__ __forceinline__ bool jacobi_rotation(float a, float b, float g, float
 }
 __device__ __forceinline__ bool jacobi_rotation(double a, double b, double g, double tol, double& cs, double& sn,
                                                 double& rel, double& t) {
-  const double ab = sqrt(a * b);
+  const double ab = sqrt(a) * sqrt(b);
   rel = ab > 0.0 ? fabs(g) / ab : 0.0;
   if (!(rel > tol)) return false;
   const double zeta = (b - a) / (2.0 * g);
@@ -1401,6 +1407,33 @@ __global__ __launch_bounds__(kRingProcPad * G) void jacobi_ring_w_kernel(const T
         qw[cc][z] = (ok && colq < l) ? c[(int64_t)colq * ldc + row] : (T)0;
       }
   }
+  // Scale invariance: the core is multiplied by an exact power of two that brings its largest entry into [1, 2)
+  // (squared column norms of a tiny or huge core would under- / overflow); sigma is scaled back on output.
+  int sexp = 0;
+  {
+    T mx = (T)0;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+      for (int z = 0; z < VW; ++z) mx = fmax(mx, fmax(fabs(pw[cc][z]), fabs(qw[cc][z])));
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    if ((tid & 63) == 0) sigma[tid >> 6] = mx;   // sigma is scratch until the end
+    __syncthreads();
+    mx = (T)0;
+    for (int wv = 0; wv < (int)((blockDim.x + 63) >> 6); ++wv) mx = fmax(mx, sigma[wv]);
+    __syncthreads();
+    if (mx > (T)0 && mx <= std::numeric_limits<T>::max()) {  // finite, non-zero
+      (void)frexp((double)mx, &sexp);
+      sexp = 1 - sexp;  // mx * 2^sexp in [1, 2)
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+        for (int z = 0; z < VW; ++z) {
+          pw[cc][z] = (T)ldexp((double)pw[cc][z], sexp);
+          qw[cc][z] = (T)ldexp((double)qw[cc][z], sexp);
+        }
+    }
+  }
   const int my_off = proc * RS + g * VW;
   // idle processors (proc >= np) form their own harmless ring of zero columns
   const int up_proc = act ? (proc + 1 >= np ? 0 : proc + 1) : proc, dn_proc = act ? (proc == 0 ? np - 1 : proc - 1) : proc;
@@ -1540,8 +1573,8 @@ __global__ __launch_bounds__(kRingProcPad * G) void jacobi_ring_w_kernel(const T
         }
       }
     if (g == 0) {
-      if (rp < k) s_out[rp] = sp > (T)0 ? sp : (T)0;
-      if (rq < k) s_out[rq] = sq > (T)0 ? sq : (T)0;
+      if (rp < k) s_out[rp] = sp > (T)0 ? (T)ldexp((double)sp, -sexp) : (T)0;
+      if (rq < k) s_out[rq] = sq > (T)0 ? (T)ldexp((double)sq, -sexp) : (T)0;
     }
   }
   if (tid == 0) {

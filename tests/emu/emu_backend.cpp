@@ -158,6 +158,16 @@ class EmuDev {
     std::memcpy(dst.p, src.p, (size_t)src.ld * src.cols_alloc * sizeof(T));
   }
   template <class T>
+  void copy_cols(const Skinny<T>& src, Skinny<T>& dst, int64_t c0, int64_t n) {
+    if (src.ld != dst.ld) throw Error(ST_EINVAL, "internal: copy_cols needs equal leading dimensions");
+    if (n > 0) std::memcpy(dst.p + c0 * dst.ld, src.p, (size_t)n * src.ld * sizeof(T));
+  }
+  template <class T>
+  void sub_inplace(Skinny<T>& y, const Skinny<T>& p) {
+    const int64_t n = y.ld * std::min(y.cols_alloc, p.cols_alloc);
+    for (int64_t i = 0; i < n; ++i) y.p[i] -= p.p[i];
+  }
+  template <class T>
   void zero_cols(Skinny<T>& s, int64_t c0, int64_t c1) {
     if (c1 > c0) std::memset(s.p + c0 * s.ld, 0, (size_t)(c1 - c0) * s.ld * sizeof(T));
   }

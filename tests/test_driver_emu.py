@@ -216,3 +216,27 @@ def test_sign_convention_short_side_vector_largest_component_positive():
         for i in range(5):
             j = int(np.argmax(np.abs(short[:, i])))
             assert short[j, i] > 0
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rank_deficient_input_still_gets_orthonormal_factors(dtype):
+    """A Householder thin-Q (random_svd.rs:38,57) is orthonormal whatever the rank of the sketch; the directions the
+    data does not determine are an arbitrary completion with zero singular values.  U and V^T of the reference's own
+    rank-3 5x5 example (random_svd.rs:155-168) and of a rank-5 60x40 matrix must be orthonormal, not zero-padded."""
+    rng = np.random.default_rng(8)
+    cases = [(orc.KNOWN_ANSWER_A.astype(dtype), 5, 12, 10, orc.KNOWN_ANSWER_S),
+             ((rng.standard_normal((60, 5)) @ rng.standard_normal((5, 40))).astype(dtype), 12, 2, 6, None),
+             (np.zeros((30, 20), dtype=dtype), 4, 2, 3, None)]
+    for a, k, q, p, s_known in cases:
+        nt = min(a.shape)
+        om = rng.standard_normal((nt, min(k + p, nt))).astype(dtype)
+        u, s, vt = emu_rsvd(a, k, q, p, omega=om)
+        tol = 1e-10 if dtype == np.float64 else 2e-4
+        assert np.max(np.abs(u.T.astype(np.float64) @ u - np.eye(k))) < tol
+        assert np.max(np.abs(vt.astype(np.float64) @ vt.T - np.eye(k))) < tol
+        ex = np.linalg.svd(a.astype(np.float64), compute_uv=False)[:k]
+        assert np.allclose(s.ravel(), ex, atol=(1e-9 if dtype == np.float64 else 2e-4) * max(ex[0], 1.0))
+        if s_known is not None:
+            assert np.allclose(s.ravel(), s_known, atol=1e-3)           # the reference's own assertion
+        rec = (u.astype(np.float64) * s.ravel()) @ vt.astype(np.float64)
+        assert np.linalg.norm(rec - a) <= (1e-9 if dtype == np.float64 else 1e-3) * max(np.linalg.norm(a), 1.0)

@@ -685,3 +685,39 @@ def test_randomised_parity_sweep(ctx):
     bad, worst = mod.run(150, seed=3, ctx=ctx, verbose=True)
     assert bad == 0, worst
     assert worst["ds"] < 1e-8 and worst["relerr"] < 1e-8 and worst["orth"] < 1e-10
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_rank_deficient_input_still_gets_orthonormal_factors(ctx, dtype):
+    """Same contract as a Householder thin-Q: U and V^T are orthonormal for rank-deficient inputs too (arbitrary
+    completion, zero singular values) -- the reference's rank-3 5x5 example and low-rank tall / fat matrices."""
+    rng = np.random.default_rng(8)
+    cases = [(orc.KNOWN_ANSWER_A.astype(dtype), 5, 12, 10),
+             ((rng.standard_normal((600, 5)) @ rng.standard_normal((5, 140))).astype(dtype), 24, 2, 6),
+             ((rng.standard_normal((90, 7)) @ rng.standard_normal((7, 900))).astype(dtype), 20, 5, 10),
+             (np.zeros((30, 20), dtype=dtype), 4, 2, 3)]
+    for a, k, q, p in cases:
+        u, s, vt = ctx.rsvd(a, k, q, p, seed=3)
+        tol = 1e-10 if dtype == np.float64 else 2e-4
+        assert np.max(np.abs(u.T.astype(np.float64) @ u - np.eye(k))) < tol, a.shape
+        assert np.max(np.abs(vt.astype(np.float64) @ vt.T - np.eye(k))) < tol, a.shape
+        ex = np.linalg.svd(a.astype(np.float64), compute_uv=False)[:k]
+        assert np.allclose(s.ravel(), ex, atol=(1e-9 if dtype == np.float64 else 2e-4) * max(ex[0], 1.0))
+
+
+@pytest.mark.parametrize("scale", [1e-9, 1e9])  # beyond ~1e-12 the reference schedule itself underflows f32: A A^T A Omega is formed before the first rescale
+def test_f32_scale_invariance(ctx, scale):
+    """The core SVD pre-scales by an exact power of two and the rotation test avoids the a*b product, so tiny or huge
+    f32 inputs give the scaled singular values and the same orthonormal factors (random_svd.rs:53-55 keeps the power
+    iteration itself normalised)."""
+    rng = np.random.default_rng(31)
+    a = (rng.standard_normal((300, 90)) * (0.97 ** np.arange(90))).astype(np.float32)
+    om = rng.standard_normal((90, 40)).astype(np.float32)
+    u0, s0, vt0 = ctx.rsvd(a, 30, 2, 10, omega=om)
+    u1, s1, vt1 = ctx.rsvd((a * np.float32(scale)).astype(np.float32), 30, 2, 10, omega=om)
+    assert np.allclose(s1.ravel() / scale, s0.ravel(), rtol=2e-4)
+    assert np.max(np.abs(u1.T.astype(np.float64) @ u1 - np.eye(30))) < 2e-4
+    assert np.max(np.abs(vt1.astype(np.float64) @ vt1.T - np.eye(30))) < 2e-4
+    rec0 = (u0.astype(np.float64) * s0.ravel()) @ vt0.astype(np.float64)
+    rec1 = (u1.astype(np.float64) * (s1.ravel() / scale)) @ vt1.astype(np.float64)
+    assert np.linalg.norm(rec1 - rec0) <= 2e-3 * np.linalg.norm(rec0)
