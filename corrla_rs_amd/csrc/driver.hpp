@@ -160,16 +160,15 @@ struct RsvdDriver {
   }
 
   // ---- thin-Q orthonormalisation (replaces y.qr().compute_thin_q(), random_svd.rs:38,57) ----
-  // Iterated Cholesky-QR on the device-computed Gram matrix: G = Y^T Y (tall GEMM + optional
-  // all-reduce), host Cholesky of the l x l G in f64, Y <- Y * R^-1 (tall GEMM).  A pass whose
-  // Gram was already within 0.25 of I leaves Y orthonormal to O(eps), so well-conditioned
-  // sketches take two passes.  Numerically singular Grams get a diagonal shift (shifted
-  // CholeskyQR, Fukaya et al. 2020); if three shifted passes do not recover full rank the
-  // deficient directions are exact-null and are dropped through an eigen-decomposition of G:
-  // the result then has r < l orthonormal columns followed by zero columns, which is how the
-  // rest of the pipeline represents "arbitrary completion" directions of a rank-deficient QR
-  // (their singular values are 0 either way; random_svd.rs:153-196 exercises this).
-  // Returns the number of non-zero (orthonormal) columns.
+  // Iterated Cholesky-QR on the device-computed Gram matrix: G = Y^T Y (tall GEMM + optional all-reduce),
+  // Cholesky factor and inverse (device kernel when l <= 176 and the optimistic path applies, host f64
+  // otherwise), Y <- Y * R^-1 (tall GEMM).  A pass whose Gram was already within 0.25 of I leaves Y orthonormal
+  // to O(eps), so well-conditioned sketches take two passes.  Numerically singular Grams get a diagonal shift
+  // (shifted CholeskyQR, Fukaya et al. 2020); if three shifted passes do not recover full rank the deficient
+  // directions are exact-null and are dropped through an eigen-decomposition of G (orthonormalize_core then
+  // returns r < l), after which complete_basis fills columns [r, l) with an orthonormal completion -- the
+  // "arbitrary completion" a Householder QR of a rank-deficient matrix carries (random_svd.rs:153-196).
+  // Returns the number of orthonormal columns (l unless the matrix has fewer rows than columns).
   // `rough`: stop after the first clean Cholesky pass -- enough for the in-loop re-orthonormalisations
   // (random_svd.rs:37-39), whose only role is to keep the sketch well conditioned; the span is unchanged.
   static constexpr int kStatusSlots = 64;
