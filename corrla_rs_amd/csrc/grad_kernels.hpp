@@ -400,18 +400,58 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
   }
   if (lane == 0) *flag = 0;
   __syncthreads();
-  for (int idx = lane; idx < n_nbrs * k; idx += 64) {
-    const int r = idx / k, d = idx - r * k;
-    const int p = nbr[q * n_nbrs + r];
-    xn[idx] = x[(int64_t)p * k + d] - (order == 1 ? x0[d] : 0.0);
+  // gather: the neighbour list first (one coalesced load), then the rows with eight independent loads in flight
+  // (a load that depends on a freshly loaded index per element would serialise two global latencies 80 times)
+  int* nidx = (int*)(flag + 2);  // [n_nbrs]
+  for (int r = lane; r < n_nbrs; r += 64) nidx[r] = nbr[q * n_nbrs + r];
+  __syncthreads();
+  const int total = n_nbrs * k;
+  for (int i0g = 0; i0g < total; i0g += 64 * 8) {
+    double val[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = i0g + u * 64 + lane;
+      val[u] = 0.0;
+      if (idx < total) {
+        const int r = idx / k, d = idx - r * k;
+        val[u] = x[(int64_t)nidx[r] * k + d] - (order == 1 ? x0[d] : 0.0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = i0g + u * 64 + lane;
+      if (idx < total) xn[idx] = val[u];
+    }
   }
-  for (int r = lane; r < n_nbrs; r += 64) yn[r] = y[nbr[q * n_nbrs + r]];
+  for (int r = lane; r < n_nbrs; r += 64) yn[r] = y[nidx[r]];
   __syncthreads();
   auto design = [&](int r, int c) -> double {
     const int a = pa[c], b = pb[c];
     if (a < 0) return 1.0;
     const double va = xn[r * k + a];
     return b < 0 ? va : va * xn[r * k + b];
+  };
+  // sum_r v(r, i) v(r, j)  (j == P: the right-hand side sum_r v(r, i) y_r).  The column descriptors are hoisted out
+  // of the loop over the neighbours, so its LDS reads are independent of one another and pipeline.
+  auto gram_entry = [&](int i, int j) -> double {
+    const int ai = pa[i], bi = pb[i];
+    const int aj = j < P ? pa[j] : -2, bj = j < P ? pb[j] : -1;
+    double s0 = 0.0, s1 = 0.0;
+    int r = 0;
+    auto term = [&](int rr) -> double {
+      const double* row = xn + rr * k;
+      double vi = ai < 0 ? 1.0 : row[ai];
+      if (bi >= 0) vi *= row[bi];
+      double vj = aj == -2 ? yn[rr] : (aj < 0 ? 1.0 : row[aj]);
+      if (bj >= 0) vj *= row[bj];
+      return vi * vj;
+    };
+    for (; r + 1 < n_nbrs; r += 2) {
+      s0 += term(r);
+      s1 += term(r + 1);
+    }
+    if (r < n_nbrs) s0 += term(r);
+    return s0 + s1;
   };
   // normal equations: M(i, j) = sum_r v(r, i) v(r, j) for j <= i, M(i, P) = sum_r v(r, i) y_r
   const int npair = P * (P + 1) / 2 + P;
@@ -426,9 +466,7 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
       i = e - P * (P + 1) / 2;
       j = P;
     }
-    double s = 0.0;
-    for (int r = 0; r < n_nbrs; ++r) s += design(r, i) * (j == P ? yn[r] : design(r, j));
-    M[i * LM + j] = s;
+    M[i * LM + j] = gram_entry(i, j);
   }
   __syncthreads();
   // Cholesky (lower, in place) with a relative pivot test; a failed pivot restarts once with a ridge
@@ -437,24 +475,21 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
   double ridge = 0.0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     bool ok = true;
+    // right-looking: after step j the trailing lower triangle holds M - L(:, :j+1) L(:, :j+1)^T; lane = column, so the
+    // lanes of a wave read consecutive addresses of one row (no LDS bank conflicts) and L(i, j) is a broadcast
     for (int j = 0; j < P; ++j) {
-      // row j of L: L(j, c) for c < j is final; pivot
-      double s = 0.0;
-      for (int c = lane; c < j; c += 64) s += M[j * LM + c] * M[j * LM + c];
-      s = wave_sum_f64(s);
-      const double piv = M[j * LM + j] + ridge - s;
+      const double piv = M[j * LM + j] + ridge;
       if (!(piv > 1e-13 * dmax)) {
         ok = false;
         break;  // uniform
       }
-      const double ljj = sqrt(piv);
+      const double ljj = sqrt(piv), inv = 1.0 / ljj;
       __syncthreads();
-      if (lane == 0) M[j * LM + j] = ljj;
-      // column j below the diagonal: L(i, j) = (M(i, j) - sum_c L(i, c) L(j, c)) / ljj
-      for (int i = j + 1 + lane; i < P; i += 64) {
-        double t = M[i * LM + j];
-        for (int c = 0; c < j; ++c) t -= M[i * LM + c] * M[j * LM + c];
-        M[i * LM + j] = t / ljj;
+      for (int i = j + lane; i < P; i += 64) M[i * LM + j] = (i == j) ? ljj : M[i * LM + j] * inv;
+      __syncthreads();
+      for (int c = j + 1 + lane; c < P; c += 64) {
+        const double lcj = M[c * LM + j];
+        for (int i = c; i < P; ++i) M[i * LM + c] -= M[i * LM + j] * lcj;
       }
       __syncthreads();
     }
@@ -470,9 +505,7 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
       while (i * (i + 1) / 2 > e) --i;
       while ((i + 1) * (i + 2) / 2 <= e) ++i;
       const int j = e - i * (i + 1) / 2;
-      double s = 0.0;
-      for (int r = 0; r < n_nbrs; ++r) s += design(r, i) * design(r, j);
-      M[i * LM + j] = s;
+      M[i * LM + j] = gram_entry(i, j);
     }
     ridge = 1e-10 * dmax;
     if (lane == 0) *flag = 1;
@@ -518,7 +551,7 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
 }
 inline size_t grad_fit_lds_bytes(int k, int n_nbrs, int order) {
   const int P = order == 1 ? k + 1 : k + k * (k + 1) / 2;
-  return ((size_t)n_nbrs * k + n_nbrs + (size_t)P * (P + 1) + k + P) * 8 + (size_t)(2 * P + 4) * 4 + 64;
+  return ((size_t)n_nbrs * k + n_nbrs + (size_t)P * (P + 1) + k + P) * 8 + (size_t)(2 * P + 4 + n_nbrs) * 4 + 64;
 }
 
 }  // namespace k
