@@ -176,6 +176,7 @@ struct RsvdDriver {
   struct Pending {
     int slot, npass;
     bool rough;
+    int per_pass;  // status records per pass: 1 (single factorisation) or 2 (2 x 2 blocked)
   };
   bool defer_status_ = false;
   void* st_pool_ = nullptr;
@@ -242,7 +243,7 @@ struct RsvdDriver {
       if (defer) {
         // verified once at the end of random_svd_tall; a record that is not clean reruns the whole
         // computation through the host-controlled path below
-        pending_.push_back({st_used_, npass, rough});
+        pending_.push_back({st_used_, npass, rough, 1});
         st_used_ += npass;
         phase(tm.qr_gram_ms, qt0);
         return l;
@@ -255,6 +256,63 @@ struct RsvdDriver {
         if (fail[pass] == 3) throw Error(ST_ENUMERIC, "non-finite Gram matrix in orthonormalisation");
       if (fail[0] == 2) return 0;  // Y is the zero matrix
       const bool ok = fail[0] == 0 && (rough || (fail[1] == 0 && dev_i[1] <= 0.25f));
+      if (ok) return l;
+    }
+    if (!dev.template device_chol_fits<T>(l) && dev.template device_chol_blocked_fits<T>(l)) {
+      // 176 < l <= 352: the same optimistic CholeskyQR2, with the factor-and-invert done 2 x 2 blocked on the device:
+      //   G = [G11 G12; G12^T G22],  R11 = chol(G11), R12 = R11^-T G12, R22 = chol(G22 - R12^T R12),
+      //   R^-1 = [X11, -X11 R12 X22; 0, X22]  with X = R^-1 of the diagonal blocks (chol_inv_kernel).
+      PhaseTimer qt0;
+      const int npass = rough ? 1 : 2;
+      const int64_t n1 = round_up((l + 1) / 2, (int64_t)4), n2 = l - n1;
+      Skinny<T> gd0 = dev.template alloc_skinny<T>(l, l);
+      const bool defer = defer_status_ && st_used_ + 2 * npass <= kStatusSlots;
+      void* st_dev = defer ? (void*)((char*)st_pool_ + (size_t)st_used_ * kStatusBytes) : dev.alloc_bytes(4 * kStatusBytes);
+      const double eps0 = (double)std::numeric_limits<T>::epsilon();
+      T* minus_one = dev.template alloc_scalar<T>(1);
+      dev.fill_const(minus_one, (int64_t)1, (T)-1);
+      for (int pass = 0; pass < npass; ++pass) {
+        Skinny<T> yv = y.view_cols(l);
+        dev.gemm_nn(as_rowmajor_transposed(y, l), yv, gd0, kNone);
+        if (sharded) dev.allreduce(gd0.p, (size_t)gd0.ld * (size_t)gd0.cols_alloc);
+        Skinny<T> g11 = dev.template alloc_skinny<T>(n1, n1), g12 = dev.template alloc_skinny<T>(n1, n2);
+        Skinny<T> g22 = dev.template alloc_skinny<T>(n2, n2), x11 = dev.template alloc_skinny<T>(n1, n1);
+        Skinny<T> x22 = dev.template alloc_skinny<T>(n2, n2), r12 = dev.template alloc_skinny<T>(n1, n2);
+        Skinny<T> t22 = dev.template alloc_skinny<T>(n2, n2), t12 = dev.template alloc_skinny<T>(n1, n2);
+        Skinny<T> x12 = dev.template alloc_skinny<T>(n1, n2), md0 = dev.template alloc_skinny<T>(l, l);
+        dev.copy_block(gd0, 0, 0, n1, n1, g11, 0, 0);
+        dev.copy_block(gd0, 0, n1, n1, n2, g12, 0, 0);
+        dev.copy_block(gd0, n1, n1, n2, n2, g22, 0, 0);
+        dev.chol_inv(g11, n1, (T)(4.0 * eps0), x11, st_dev, 2 * pass);
+        dev.gemm_nn(as_rowmajor_transposed(x11, n1), g12, r12, kNone);  // R12 = X11^T G12
+        dev.gemm_nn(as_rowmajor_transposed(r12, n2), r12, t22, kNone);  // R12^T R12
+        dev.sub_inplace(g22, t22);                                      // Schur complement
+        dev.chol_inv(g22, n2, (T)(4.0 * eps0), x22, st_dev, 2 * pass + 1);
+        dev.gemm_tn(as_rowmajor_transposed(r12, n2), x22, t12, kNone);  // R12 X22
+        dev.gemm_tn(as_rowmajor_transposed(x11, n1), t12, x12, minus_one);  // -X11 R12 X22
+        dev.copy_block(x11, 0, 0, n1, n1, md0, 0, 0);
+        dev.copy_block(x12, 0, 0, n1, n2, md0, 0, n1);
+        dev.copy_block(x22, 0, 0, n2, n2, md0, n1, n1);
+        dev.gemm_tn(as_rowmajor_transposed(y, l), md0, tmp, kNone);
+        std::swap(y.p, tmp.p);
+        ++tm.qr_passes;
+      }
+      if (defer) {
+        pending_.push_back({st_used_, npass, rough, 2});
+        st_used_ += 2 * npass;
+        phase(tm.qr_gram_ms, qt0);
+        return l;
+      }
+      int fail[4] = {0, 0, 0, 0};
+      float min_ratio[4], dev_i[4];
+      dev.read_chol_status(st_dev, 2 * npass, fail, min_ratio, dev_i);
+      phase(tm.qr_gram_ms, qt0);
+      bool ok = true;
+      for (int i = 0; i < 2 * npass; ++i) {
+        if (fail[i] == 3) throw Error(ST_ENUMERIC, "non-finite Gram matrix in orthonormalisation");
+        ok = ok && fail[i] == 0;
+      }
+      if (ok && !rough) ok = dev_i[2 * (npass - 1)] <= 0.25f && dev_i[2 * (npass - 1) + 1] <= 0.25f;
       if (ok) return l;
     }
     const double eps = (double)std::numeric_limits<T>::epsilon();
@@ -408,7 +466,7 @@ struct RsvdDriver {
   // u_tall: mt x k, v_tall: nt x k (both skinny, allocated by the caller), s_dev: k values (device).
   void random_svd_tall(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
                        T* s_dev, Skinny<T>& v_tall) {
-    if (dev.template device_chol_fits<T>(l)) {
+    if (dev.template device_chol_fits<T>(l) || dev.template device_chol_blocked_fits<T>(l)) {
       // Optimistic run: every Cholesky-QR status record is checked once, after the last kernel is enqueued
       // (no host synchronisation inside the call).  A record that is not clean (rank deficiency, zero or
       // non-finite input, ...) repeats the computation with the host in the loop.
@@ -436,9 +494,11 @@ struct RsvdDriver {
     float min_ratio[kStatusSlots], dev_i[kStatusSlots];
     dev.read_chol_status(st_pool_, st_used_, fail, min_ratio, dev_i);
     for (const Pending& p : pending_) {
-      const int f0 = fail[p.slot];
-      if (f0 != 0) return false;
-      if (!p.rough && (fail[p.slot + 1] != 0 || !(dev_i[p.slot + 1] <= 0.25f))) return false;
+      for (int i = 0; i < p.npass * p.per_pass; ++i)
+        if (fail[p.slot + i] != 0) return false;
+      if (!p.rough)
+        for (int i = 0; i < p.per_pass; ++i)
+          if (!(dev_i[p.slot + (p.npass - 1) * p.per_pass + i] <= 0.25f)) return false;
     }
     return true;
   }

@@ -326,6 +326,20 @@ class HipDev {
     return l <= 4096 && k::chol_inv_fits((int)l, sizeof(T)) && !no_device_chol_;
   }
   template <class T>
+  bool device_chol_blocked_fits(int64_t l) const {
+    const int64_t n1 = round_up((l + 1) / 2, (int64_t)4);
+    return l > 8 && l <= 4096 && k::chol_inv_fits((int)n1, sizeof(T)) && !no_device_chol_;
+  }
+  // dst(dr0 + i, dc0 + j) <- src(r0 + i, c0 + j), i < rows, j < cols
+  template <class T>
+  void copy_block(const Skinny<T>& src, int64_t r0, int64_t c0, int64_t rows, int64_t cols, Skinny<T>& dst, int64_t dr0,
+                  int64_t dc0) {
+    if (rows <= 0 || cols <= 0) return;
+    CORRLA_HIP(hipMemcpy2DAsync(dst.p + dc0 * dst.ld + dr0, (size_t)dst.ld * sizeof(T), src.p + c0 * src.ld + r0,
+                                (size_t)src.ld * sizeof(T), (size_t)rows * sizeof(T), (size_t)cols, hipMemcpyDeviceToDevice,
+                                stream));
+  }
+  template <class T>
   void chol_inv(const Skinny<T>& g, int64_t r, T piv_rel, Skinny<T>& m_out, void* st_dev, int slot) {
     // m_out comes zero-filled from alloc_skinny and only its upper triangle is ever written
     hipLaunchKernelGGL((k::chol_inv_kernel<T>), dim3(1), dim3(k::chol_inv_threads((int)r)),

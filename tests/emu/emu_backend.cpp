@@ -184,6 +184,16 @@ class EmuDev {
     return l <= 176 && !std::getenv("CORRLA_EMU_NO_DEVICE_CHOL");
   }
   template <class T>
+  bool device_chol_blocked_fits(int64_t l) const {
+    return l > 8 && l <= 276 && !std::getenv("CORRLA_EMU_NO_DEVICE_CHOL");
+  }
+  template <class T>
+  void copy_block(const Skinny<T>& src, int64_t r0, int64_t c0, int64_t rows, int64_t cols, Skinny<T>& dst, int64_t dr0,
+                  int64_t dc0) {
+    for (int64_t j = 0; j < cols; ++j)
+      for (int64_t i = 0; i < rows; ++i) dst.p[(dc0 + j) * dst.ld + dr0 + i] = src.p[(c0 + j) * src.ld + r0 + i];
+  }
+  template <class T>
   void chol_inv(const Skinny<T>& g, int64_t r, T piv_rel, Skinny<T>& m_out, void* st_dev, int slot) {
     EmuCholStatus* st = (EmuCholStatus*)st_dev + slot;
     std::vector<double> a((size_t)r * r);

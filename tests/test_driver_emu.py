@@ -240,3 +240,24 @@ def test_rank_deficient_input_still_gets_orthonormal_factors(dtype):
             assert np.allclose(s.ravel(), s_known, atol=1e-3)           # the reference's own assertion
         rec = (u.astype(np.float64) * s.ravel()) @ vt.astype(np.float64)
         assert np.linalg.norm(rec - a) <= (1e-9 if dtype == np.float64 else 1e-3) * max(np.linalg.norm(a), 1.0)
+
+
+@pytest.mark.parametrize("l", [177, 190, 266])
+def test_emu_blocked_cholesky_qr_for_wide_sketches(l):
+    """176 < l <= 352 takes the 2 x 2 blocked device factor-and-invert (driver.hpp: orthonormalize_core); the result
+    must match the oracle like every other width, and a rank-deficient input must fall back cleanly."""
+    rng = np.random.default_rng(l)
+    m, n = 420, 280
+    a = rng.standard_normal((m, n)) * (0.995 ** np.arange(n))
+    k, p = l - 10, 10
+    om = rng.standard_normal((n, l))
+    u, s, vt = emu_rsvd(a, k, 2, p, omega=om)
+    uo, so, vto = orc.random_svd(a, k, 2, p, omega=om)
+    assert np.max(np.abs(s - so)) <= 1e-10 * so[0, 0]
+    assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-9
+    assert np.max(np.abs(u.T @ u - np.eye(k))) < 1e-11 and np.max(np.abs(vt @ vt.T - np.eye(k))) < 1e-11
+    low = rng.standard_normal((m, 9)) @ rng.standard_normal((9, n))
+    u, s, vt = emu_rsvd(low, k, 1, p, omega=om)
+    ex = np.linalg.svd(low, compute_uv=False)[:k]
+    assert np.allclose(s.ravel(), ex, atol=1e-9 * ex[0])
+    assert np.max(np.abs(u.T @ u - np.eye(k))) < 1e-10
