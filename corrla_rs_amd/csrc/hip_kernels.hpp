@@ -79,6 +79,9 @@ constexpr int kRowBytes = 256;  // LDS row of the k-contiguous images
 #ifndef CORRLA_PD
 #define CORRLA_PD 4
 #endif
+#ifndef CORRLA_GEMM_DEFER
+#define CORRLA_GEMM_DEFER 1
+#endif
 constexpr int kPrefetchSteps = CORRLA_PD;  // LDS fragment reads run this many MFMA steps ahead
 constexpr int kLoaders = 4;      // LDS-DMA loader waves per workgroup (besides the 4 MFMA waves); must divide 4
 // A workgroup owns 64*MW outer indices (4 waves x MW 16-wide MFMA tiles each).  MW = 2 halves the
@@ -326,12 +329,33 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
   // Step st = gq*NT + t consumes one skinny fragment a(st) and the MW big-operand fragments b(gq) in
   // MW*VEC MFMAs.  Reads for step st+PD are issued before the MFMAs of step st; the wait for step
   // st leaves exactly the younger reads (steps st+1..st+PD) in flight.
-  auto compute = [&](int buf) {
-    constexpr int NS = 4 * NT;
-    constexpr int PD = kPrefetchSteps;
+  // The MFMAs of the last kDefer steps of a tile are issued AFTER the next tile's barrier and first fragment reads:
+  // their operands are already in registers, so they fill the bubble (barrier -> LDS latency -> first MFMA) that
+  // every tile otherwise pays.
+  constexpr int NS = 4 * NT;
+  constexpr int PD = kPrefetchSteps;
+  constexpr int kDefer = (NT >= 2 && CORRLA_GEMM_DEFER) ? 2 : 0;
+  vec_t afr[NS];
+  vec_t bfr[4][MW];
+  auto mfma_step = [&](auto ic) {
+    constexpr int st = decltype(ic)::value;
+    constexpr int gq = st / NT, t = st % NT;
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(afr[st][j], bfr[gq][mw][j], acc[mw][t]);
+  };
+  auto compute = [&](int buf, bool have_prev) {
     const unsigned sb = (unsigned)(buf * STAGE);
-    vec_t afr[NS];
-    vec_t bfr[4][MW];
+    // fragments of the previous tile's deferred steps: copied so that this tile's reads may reuse the arrays
+    vec_t da[kDefer > 0 ? kDefer : 1];
+    vec_t db[MW];
+    if constexpr (kDefer > 0) {
+#pragma unroll
+      for (int d = 0; d < kDefer; ++d) da[d] = afr[NS - kDefer + d];
+#pragma unroll
+      for (int mw = 0; mw < MW; ++mw) db[mw] = bfr[3][mw];
+    }
     auto read_step = [&](auto ic) {  // all reads that step `st` needs and that are not issued yet
       constexpr int st = decltype(ic)::value;
       constexpr int gq = st / NT, t = st % NT;
@@ -344,6 +368,19 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
       lds_read_b128<t * 16 * kRowBytes>(afr[st], a_off[gq] + sb);
     };
     static_for<0, (PD < NS ? PD : NS)>(read_step);
+    if constexpr (kDefer > 0) {
+      if (have_prev) {
+        static_for<0, kDefer>([&](auto id) {
+          constexpr int d = decltype(id)::value;
+          constexpr int t = (NS - kDefer + d) % NT;
+          lds_tie(da[d]);  // pins these MFMAs after the barrier and the reads above
+#pragma unroll
+          for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(da[d][j], db[mw][j], acc[mw][t]);
+        });
+      }
+    }
     static_for<0, NS>([&](auto ic) {
       constexpr int st = decltype(ic)::value;
       constexpr int gq = st / NT, t = st % NT;
@@ -356,16 +393,16 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
       if constexpr (t == 0) {
         static_for<0, MW>([&](auto im) { lds_tie(bfr[gq][decltype(im)::value]); });
       }
-#pragma unroll
-      for (int mw = 0; mw < MW; ++mw)
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(afr[st][j], bfr[gq][mw][j], acc[mw][t]);
+      if constexpr (st < NS - kDefer) mfma_step(ic);
     });
   };
 
   for (int i = 0; i < nk; ++i) {
     wg_barrier();  // matches the loaders' barrier: tile i is in LDS (all of this wave's LDS reads are retired)
-    compute(i % gemm_stages(MW, NT));
+    compute(i % gemm_stages(MW, NT), i > 0);
+  }
+  if constexpr (kDefer > 0) {
+    if (nk > 0) static_for<NS - kDefer, NS>(mfma_step);
   }
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw)
@@ -493,12 +530,32 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
                                   (ncol % VEC) * (int)sizeof(T));
   }
 
-  auto compute = [&](int buf) {
-    constexpr int NS = 4 * NT;
-    constexpr int PD = kPrefetchSteps;
+  // same deferral of the last steps' MFMAs across the tile barrier as in gemm_nn_kernel
+  constexpr int NS = 4 * NT;
+  constexpr int PD = kPrefetchSteps;
+  constexpr int kDefer = (NT >= 2 && CORRLA_GEMM_DEFER) ? 2 : 0;
+  vec_t afr[NS];
+  T bfr[4][MW][VEC];
+  auto mfma_step = [&](auto ic) {
+    constexpr int st = decltype(ic)::value;
+    constexpr int gq = st / NT, t = st % NT;
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(afr[st][j], bfr[gq][mw][j], acc[mw][t]);
+  };
+  auto compute = [&](int buf, bool have_prev) {
     const unsigned sb = (unsigned)(buf * STAGE);
-    vec_t afr[NS];
-    T bfr[4][MW][VEC];
+    vec_t da[kDefer > 0 ? kDefer : 1];
+    T db[MW][VEC];
+    if constexpr (kDefer > 0) {
+#pragma unroll
+      for (int d = 0; d < kDefer; ++d) da[d] = afr[NS - kDefer + d];
+#pragma unroll
+      for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) db[mw][j] = bfr[3][mw][j];
+    }
     auto read_step = [&](auto ic) {
       constexpr int st = decltype(ic)::value;
       constexpr int gq = st / NT, t = st % NT;
@@ -511,6 +568,19 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
       lds_read_b128<t * 16 * kRowBytes>(afr[st], a_off[gq] + sb);
     };
     static_for<0, (PD < NS ? PD : NS)>(read_step);
+    if constexpr (kDefer > 0) {
+      if (have_prev) {
+        static_for<0, kDefer>([&](auto id) {
+          constexpr int d = decltype(id)::value;
+          constexpr int t = (NS - kDefer + d) % NT;
+          lds_tie(da[d]);
+#pragma unroll
+          for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(da[d][j], db[mw][j], acc[mw][t]);
+        });
+      }
+    }
     static_for<0, NS>([&](auto ic) {
       constexpr int st = decltype(ic)::value;
       constexpr int gq = st / NT, t = st % NT;
@@ -522,16 +592,16 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
       if constexpr (t == 0) {
         static_for<0, MW * VEC>([&](auto iq) { lds_tie(bfr[gq][decltype(iq)::value / VEC][decltype(iq)::value % VEC]); });
       }
-#pragma unroll
-      for (int mw = 0; mw < MW; ++mw)
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(afr[st][j], bfr[gq][mw][j], acc[mw][t]);
+      if constexpr (st < NS - kDefer) mfma_step(ic);
     });
   };
 
   for (int i = 0; i < nk; ++i) {
     wg_barrier();
-    compute(i % gemm_stages(MW, NT));
+    compute(i % gemm_stages(MW, NT), i > 0);
+  }
+  if constexpr (kDefer > 0) {
+    if (nk > 0) static_for<NS - kDefer, NS>(mfma_step);
   }
 #pragma unroll
   for (int mw = 0; mw < MW; ++mw)
