@@ -30,7 +30,7 @@ CPU_SAMPLE = 16384             # cpu_baseline runs the oracle on the CPU_SAMPLE^
 CPU_THREADS = 16               # a 1-GPU box's CPU share; OpenBLAS is pinned to this many threads
 # HBM bytes per sketch launch from rocprofv3 PMC passes on this kernel/config (not collected live):
 # FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, separate --pmc runs
-TRAFFIC_BYTES_PER_LAUNCH = 1.151e9 + 19.5e6
+TRAFFIC_BYTES_PER_LAUNCH = 1.152e9 + 18.5e6 + 19.0e6 + 9.2e6  # gemm_nn FETCH x2 + WRITE, slab_reduce FETCH x2 + WRITE
 TRAFFIC_SOURCE = "profiles/r01_pmc_sketch_gemm_summary.txt"
 
 
