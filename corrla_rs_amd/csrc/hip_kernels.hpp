@@ -80,7 +80,7 @@ constexpr int kRowBytes = 256;  // LDS row of the k-contiguous images
 #define CORRLA_PD 4
 #endif
 #ifndef CORRLA_GEMM_DEFER
-#define CORRLA_GEMM_DEFER 1
+#define CORRLA_GEMM_DEFER 2  // pipeline steps whose MFMAs are issued after the next tile's barrier (0 = off)
 #endif
 constexpr int kPrefetchSteps = CORRLA_PD;  // LDS fragment reads run this many MFMA steps ahead
 constexpr int kLoaders = 4;      // LDS-DMA loader waves per workgroup (besides the 4 MFMA waves); must divide 4
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
   // every tile otherwise pays.
   constexpr int NS = 4 * NT;
   constexpr int PD = kPrefetchSteps;
-  constexpr int kDefer = (NT >= 2 && CORRLA_GEMM_DEFER) ? 2 : 0;
+  constexpr int kDefer = (NT >= 2 && NS - CORRLA_GEMM_DEFER >= PD) ? (CORRLA_GEMM_DEFER < NT ? CORRLA_GEMM_DEFER : NT) : 0;
   vec_t afr[NS];
   vec_t bfr[4][MW];
   auto mfma_step = [&](auto ic) {
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
   // same deferral of the last steps' MFMAs across the tile barrier as in gemm_nn_kernel
   constexpr int NS = 4 * NT;
   constexpr int PD = kPrefetchSteps;
-  constexpr int kDefer = (NT >= 2 && CORRLA_GEMM_DEFER) ? 2 : 0;
+  constexpr int kDefer = (NT >= 2 && NS - CORRLA_GEMM_DEFER >= PD) ? (CORRLA_GEMM_DEFER < NT ? CORRLA_GEMM_DEFER : NT) : 0;
   vec_t afr[NS];
   T bfr[4][MW][VEC];
   auto mfma_step = [&](auto ic) {
