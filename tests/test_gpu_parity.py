@@ -504,6 +504,17 @@ def test_dmdc_reference_test_on_gpu(ctx, nx, nt):
     assert np.max(np.abs(pg[:, :20] - po[:, :20])) < 5e-2 * np.max(np.abs(po[:, :20]))
 
 
+def test_drop_in_pydmdc_class(ctx):
+    """`from corrla_rs import PyDMDc` (examples/benchmark_dmd.py:12,119-124): constructor (x, u, n_modes, n_iters) with
+    dt = 1, predict(x0, u) = predict_multiple (lib_math_utils_py.rs:254-283)."""
+    from corrla_rs import PyDMDc
+    from oracle import callers_oracle as co
+    snaps, u = co.dmdc_reference_test_data(50, 40)
+    m = PyDMDc(snaps, u, 14, 40)
+    pred = m.predict(snaps[:, 0:1], u)
+    assert pred.shape[0] == 50 and np.max(np.abs(pred[:, 19] - snaps[:, 20])) < 5e-2
+
+
 def test_pod_modes_and_active_ss_fit_svd(ctx):
     import corrla_rs_amd as cr
     from oracle import callers_oracle as co
