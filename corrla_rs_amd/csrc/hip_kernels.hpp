@@ -2335,12 +2335,19 @@ __global__ void column_sign_kernel(const T* v, int64_t ld, int64_t rows, T* sign
   const T* col = v + (int64_t)j * ld;
   T best = (T)-1;
   int64_t best_i = 0;
-  for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) {
-    const T a = fabs(col[i]);
-    if (a > best) {
-      best = a;
-      best_i = i;
+  for (int64_t i0 = threadIdx.x; i0 < rows; i0 += 4 * (int64_t)blockDim.x) {  // four loads in flight
+    T a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * (int64_t)blockDim.x;
+      a[u] = i < rows ? fabs(col[i]) : (T)-1;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (a[u] > best) {  // increasing i: the first maximum wins, as before
+        best = a[u];
+        best_i = i0 + u * (int64_t)blockDim.x;
+      }
   }
   __shared__ T sb[256];
   __shared__ int64_t si[256];
