@@ -210,8 +210,8 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
       throw Error(ST_EINVAL, "n_pts and n_nbrs must exceed k + 1 (order 1) / k (k + 3) / 2 (order 2)");
     if (n_nbrs > n_pts) throw Error(ST_EINVAL, "n_nbrs exceeds the number of support points");
     if (n_nbrs > k::kGradMaxNbr) throw Error(ST_EINVAL, "more than 160 neighbours are not supported");
-    const int P = est_order == 1 ? (int)kf + 1 : (int)(kf + kf * (kf + 1) / 2);
-    if (P > k::kGradMaxCols) throw Error(ST_EINVAL, "the design matrix would have more than 65 columns (order 2 needs k <= 9)");
+    const int P = est_order == 1 ? (int)kf + 1 : (int)(kf + kf * (kf + 1) / 2 + 1);
+    if (P > k::kGradMaxCols) throw Error(ST_EINVAL, "the design matrix would have more than 66 columns (order 2 needs k <= 10)");
     if (ldg < kf) throw Error(ST_EINVAL, "ldg < k");
     if (n_pts > 0x7fffffff || n_q * n_nbrs > ((int64_t)1 << 40)) throw Error(ST_EINVAL, "point set too large");
     std::lock_guard<std::mutex> lk(c->mu);

@@ -7,10 +7,13 @@
 //                     kd-tree degenerates to that anyway): 16 queries per workgroup share every LDS-staged chunk of
 //                     64 support points; each wave keeps a sorted top-n list per query in LDS (ties -> lower index);
 //   grad_fit_kernel : one wave per query: gathers the neighbours, forms the normal equations of the reference's
-//                     design matrix ([x - x0, 1] for order 1 -- the slopes do not depend on the shift --, [x, x_a x_b]
-//                     without a constant for order 2, exactly build_vandermonde) in LDS, Cholesky-solves them and
-//                     writes the gradient (order 2: the analytic gradient of the fitted quadratic; the reference
-//                     takes forward differences with eps = 1e-10, which agree to ~1e-6 relative).
+//                     design matrix ([x, 1] for order 1, [x, x_a x_b (a <= b), 1] for order 2: linear_fit and
+//                     build_vandermonde, stats_corr.rs:146-159, 198-207) in LDS, Cholesky-solves them and writes the
+//                     gradient.  Both polynomial spaces are translation invariant, so the fit is formed in the
+//                     coordinates x - x0 (well-conditioned normal equations; the same fitted polynomial whenever
+//                     the design has full column rank) and the gradient at x0 is just the linear coefficients
+//                     (order 2: the reference differentiates its quadratic by forward differences with eps = 1e-10,
+//                     which agree with the analytic gradient to ~1e-6 relative).
 // The gradient matrix is written in the reference's k x N column-major layout (N rows of k contiguous values), which
 // is the row-major tall matrix the RSVD kernels take directly.
 #pragma once
@@ -24,7 +27,7 @@ namespace k {
 
 constexpr int kGradMaxDim = 64;    // features k
 constexpr int kGradMaxNbr = 160;   // neighbours per query
-constexpr int kGradMaxCols = 65;   // design-matrix columns: k + 1 (order 1), k + k (k + 1) / 2 (order 2)
+constexpr int kGradMaxCols = 66;   // design-matrix columns: k + 1 (order 1), k + k (k + 1) / 2 + 1 (order 2)
 constexpr int kKnnQueriesPerWave = 4, kKnnWaves = 4, kKnnQueries = kKnnQueriesPerWave * kKnnWaves;
 
 // xt (k x ldt, dimension-major) <- x (n x k, row-major)
@@ -366,9 +369,9 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
                                                       const int* __restrict__ nbr, int n_nbrs, int order, double out_scale,
                                                       double* g, int64_t ldg, int* status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int P = order == 1 ? k + 1 : k + k * (k + 1) / 2;  // design columns
-  const int LM = P + 1;                                    // row pitch of M (the right-hand side is column P)
-  double* xn = (double*)smem;                 // [n_nbrs][k] neighbour coordinates (minus x0 for order 1)
+  const int P = order == 1 ? k + 1 : k + k * (k + 1) / 2 + 1;  // design columns (the constant is the last one)
+  const int LM = P + 1;                                        // row pitch of M (the right-hand side is column P)
+  double* xn = (double*)smem;                 // [n_nbrs][k] neighbour coordinates minus x0
   double* yn = xn + (size_t)n_nbrs * k;       // [n_nbrs]
   double* M = yn + n_nbrs;                    // [P][LM] normal equations, lower triangle -> Cholesky factor
   double* x0 = M + (size_t)P * LM;            // [k]
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
     if (c < k) {
       pa[c] = c;
       pb[c] = -1;
-    } else if (order == 1) {
+    } else if (c == P - 1) {
       pa[c] = -1;
       pb[c] = -1;
     }
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
       val[u] = 0.0;
       if (idx < total) {
         const int r = idx / k, d = idx - r * k;
-        val[u] = x[(int64_t)nidx[r] * k + d] - (order == 1 ? x0[d] : 0.0);
+        val[u] = x[(int64_t)nidx[r] * k + d] - x0[d];
       }
     }
 #pragma unroll
@@ -536,21 +539,14 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
   for (int m = lane; m < k; m += 64) {
     double gm = 0.0;
     if (fl != 2) {
-      gm = beta[m];
-      if (order == 2) {
-        for (int c = k; c < P; ++c) {
-          const int a = pa[c], b = pb[c];
-          if (a == m) gm += beta[c] * x0[b];
-          if (b == m) gm += beta[c] * x0[a];
-        }
-      }
+      gm = beta[m];  // d/dx_m of the polynomial in (x - x0) at x0: the quadratic terms vanish there
     }
     g[q * ldg + m] = out_scale * gm;
   }
   if (lane == 0 && status) status[q] = fl;
 }
 inline size_t grad_fit_lds_bytes(int k, int n_nbrs, int order) {
-  const int P = order == 1 ? k + 1 : k + k * (k + 1) / 2;
+  const int P = order == 1 ? k + 1 : k + k * (k + 1) / 2 + 1;
   return ((size_t)n_nbrs * k + n_nbrs + (size_t)P * (P + 1) + k + P) * 8 + (size_t)(2 * P + 4 + n_nbrs) * 4 + 64;
 }
 

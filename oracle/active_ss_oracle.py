@@ -49,9 +49,9 @@ def mat_col_interactions(x, include_self):
 
 
 def build_vandermonde(x, include_self=True):
-    """stats_corr.rs:201-207: hstack(x, interactions) -- note: NO constant column."""
+    """stats_corr.rs:198-207: hstack(x, interactions, ones) -- the constant column is the LAST one."""
     x = np.asarray(x, np.float64)
-    return np.hstack([x, mat_col_interactions(x, include_self)])
+    return np.hstack([x, mat_col_interactions(x, include_self), np.ones((x.shape[0], 1))])
 
 
 def linear_fit(x, y):
@@ -87,6 +87,22 @@ def jac_from_quad(x0, coeffs, eps=1.0e-10):
     return out
 
 
+def jac_of_quad_exact(x0, coeffs):
+    """NOT in the reference: the exact gradient of the quadratic quad_fit returned (columns as in build_vandermonde), used
+    by the tests to separate the fit itself from the ~1e-6 |y| rounding noise of the reference's forward differences."""
+    x0 = np.asarray(x0, np.float64).ravel()
+    k = x0.size
+    c = np.asarray(coeffs, np.float64).ravel()
+    g = c[:k].copy()
+    col = k
+    for a in range(k):
+        for b in range(a, k):
+            g[a] += c[col] * x0[b]
+            g[b] += c[col] * x0[a]
+            col += 1
+    return g.reshape(1, -1)
+
+
 class PolyGradientEstimator:
     """active_subspaces.rs:21-141."""
 
@@ -96,6 +112,7 @@ class PolyGradientEstimator:
         self.est_order, self.n_nbrs, self.k = int(est_order), int(n_nbrs), self.x_mat.shape[1]
         if self.est_order not in (1, 2):
             raise ValueError("Not implemented est order")   # the reference panics (:60)
+        self.exact_quad_gradient = False   # test hook, see jac_of_quad_exact
 
     def nearest_points(self, x0):
         idx = nearest_indices(self.x_mat, x0, self.n_nbrs)
@@ -112,6 +129,8 @@ class PolyGradientEstimator:
         if not (self.x_mat.shape[0] > need and self.n_nbrs > need):         # asserts at :129-130
             raise ValueError("quadratic fit needs more than k (k + 3) / 2 samples and neighbours")
         xn, yn = self.nearest_points(x0)
+        if self.exact_quad_gradient:
+            return jac_of_quad_exact(x0, quad_fit(xn, yn))
         return jac_from_quad(x0, quad_fit(xn, yn))
 
 

@@ -63,7 +63,18 @@ def test_quadratic_gradient_matches_analytic_gradient_of_a_quadratic():
     q = rng.standard_normal((k, k))
     q = q + q.T
     b = rng.standard_normal(k)
-    y = 0.5 * np.einsum("ni,ij,nj->n", x, q, x) + x @ b          # no constant term: quad_fit has none either
+    y = 0.5 * np.einsum("ni,ij,nj->n", x, q, x) + x @ b + 3.75   # build_vandermonde carries the constant column
     est = aso.PolyGradientEstimator(x, y, 2, 40)
     for x0 in x[:5]:
-        assert np.allclose(est.grad_at(x0).ravel(), q @ x0 + b, rtol=0, atol=2e-5)   # forward differences, eps = 1e-10
+        # forward differences with eps = 1e-10: rounding noise ~ |y| * 2e-16 / 1e-10
+        assert np.allclose(est.grad_at(x0).ravel(), q @ x0 + b, rtol=0, atol=1e-4)
+    est.exact_quad_gradient = True
+    for x0 in x[:5]:
+        assert np.allclose(est.grad_at(x0).ravel(), q @ x0 + b, rtol=0, atol=1e-9)
+
+
+def test_vandermonde_layout_of_the_reference():
+    """stats_corr.rs:112-143, 198-207: [x, x_a x_b (a <= b, a-major), 1]; linear_fit's design is [x, 1] (:146-159)."""
+    x = np.array([[2.0, 3.0, 5.0]])
+    assert aso.build_vandermonde(x, True).tolist() == [[2, 3, 5, 4, 6, 10, 9, 15, 25, 1]]
+    assert aso.build_vandermonde(x, False).tolist() == [[2, 3, 5, 6, 10, 15, 1]]

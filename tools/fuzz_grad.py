@@ -17,13 +17,13 @@ def run(n_cases=60, seed=0, ctx=None, verbose=True):
     worst = 0.0
     for case in range(n_cases):
         order = int(rng.integers(1, 3))
-        k = int(rng.integers(1, 65)) if order == 1 else int(rng.integers(1, 10))
+        k = int(rng.integers(1, 65)) if order == 1 else int(rng.integers(1, 11))
         need = k + 1 if order == 1 else k * (k + 3) // 2
         n_nbrs = int(rng.integers(need + 1, min(160, need + 40) + 1))
         n = int(rng.integers(n_nbrs + 5, 3000))
         x = rng.standard_normal((n, k)) * rng.uniform(0.1, 10.0) + rng.uniform(-3, 3)
         w = rng.standard_normal(k)
-        y = np.sin(x @ w * 0.1) + 0.05 * (x ** 2).sum(axis=1)
+        y = np.sin(x @ w * 0.1) + 0.05 * (x ** 2).sum(axis=1) + rng.uniform(-5, 5)
         nq = int(rng.integers(1, 60))
         xq = x[rng.choice(n, size=nq, replace=False)] if rng.random() < 0.5 else rng.standard_normal((nq, k))
         os.environ["CORRLA_KNN"] = str(int(rng.integers(1, 3)))
