@@ -5,5 +5,5 @@ from .api import (Context, PcaRsvd, algorithmic_flops, default_context, power_it
                   rsvd)
 
 __version__ = "0.1.0"
-from .callers import (ActiveSsRsvd, DMDc, FittedActiveSsRsvd, PolyGradientEstimator, active_ss_fit_svd,  # noqa: E402,F401
-                      pod_modes)
+from .callers import (ActiveSsRsvd, DMDc, FittedActiveSsRsvd, PodI, PolyGradientEstimator, RbfInterp,  # noqa: E402,F401
+                      active_ss_fit_svd, pod_modes)

@@ -5,16 +5,25 @@ reference also does after its random_svd calls (k = n_modes, a few tens), writte
   pod_modes(x, n_modes)                       <- PodI::_modes            src/lib_math_utils/pod_rom.rs:53-58
   active_ss_fit_svd(grad_mat, n_comps, ...)   <- ActiveSsRsvd::fit_svd   src/lib_math_utils/active_subspaces.rs:233-250
   DMDc(x, u, dt, n_modes, n_iters)            <- DMDc::new               src/lib_math_utils/dmd_rom.rs:45-226
-                                                 (pyo3 PyDMDc, src/lib_math_utils_py.rs:222-283)
+                                                 (pyo3 PyDMDc, src/lib_math_utils_py.rs:222-283); CUDA tensors in ->
+                                                 device-resident factors and a factored predictor
+  PodI(x, t, n_modes) / RbfInterp             <- PodI, RbfInterp         src/lib_math_utils/pod_rom.rs:36-117,
+                                                 src/lib_math_utils/interp_utils.rs:11-160 (pyo3 PyPodI, PyRbfInterp)
   PolyGradientEstimator / ActiveSsRsvd / FittedActiveSsRsvd
                                               <- src/lib_math_utils/active_subspaces.rs:21-277 (the
                                                  neighbour search and the local fits run on the GPU)
-Not built here: PodI's weights and RBF interpolation (out of scope)."""
+Every product with an n_x- or N-sized dimension goes through the library's HIP GEMMs (``Context.matmul``); only
+snapshot-count- and n_modes-sized matrices are touched by numpy."""
 import numpy as np
 
-from .api import default_context, rsvd
+from .api import _is_torch, default_context, rsvd
 
-__all__ = ["pod_modes", "active_ss_fit_svd", "DMDc", "PolyGradientEstimator", "ActiveSsRsvd", "FittedActiveSsRsvd"]
+__all__ = ["pod_modes", "active_ss_fit_svd", "DMDc", "PodI", "RbfInterp", "PolyGradientEstimator", "ActiveSsRsvd",
+           "FittedActiveSsRsvd"]
+
+
+def _on_gpu(x):
+    return _is_torch(x) and x.is_cuda
 
 
 def pod_modes(x_data, n_modes, *, seed=None, omega=None, ctx=None):
@@ -121,9 +130,16 @@ class ActiveSsRsvd:
         return FittedActiveSsRsvd(vt.t().cpu().numpy().copy(), np.diag(s.cpu().numpy().ravel()), self.n_comps)
 
     def fit(self, x_mat):
+        import torch
         x = np.asarray(x_mat, dtype=np.float64)
-        g = self.grad_est.grad_mat(x)
-        c = (g @ g.T) * (1.0 / x.shape[0])                                           # :256
+        ctx = self._ctx or self.grad_est._ctx or default_context()
+        dev = torch.device(f"cuda:{ctx.device}")
+        ge = self.grad_est
+        g, ge.n_regularised = ctx.grad_mat(torch.as_tensor(ge.x_mat, device=dev), torch.as_tensor(ge.y, device=dev),
+                                           ge.est_order, ge.n_nbrs, torch.as_tensor(np.ascontiguousarray(x), device=dev))
+        gt = g.t()                                                                   # N x k row-major, on the device
+        c = ctx.matmul(gt, gt, trans=True).cpu().numpy() * (1.0 / x.shape[0])        # G G^T / N  (k x k), :256
+        c = 0.5 * (c + c.T)
         w, v = np.linalg.eigh(c)
         order = np.argsort(-w, kind="stable")                                        # sort_evd, mat_utils.rs:459-478
         return FittedActiveSsRsvd(v[:, order], np.diag(w[order]), self.n_comps)
@@ -145,6 +161,10 @@ class DMDc:
 
     def __init__(self, x_data, u_data, dt, n_modes, n_iters, *, seed=None, omega_x=None, omega_y=None, ctx=None):
         c = ctx or default_context()
+        self.on_device = _on_gpu(x_data)
+        if self.on_device:
+            self._init_device(c, x_data, u_data, float(dt), int(n_modes), int(n_iters), seed, omega_x, omega_y)
+            return
         x_data = np.asarray(x_data, np.float64)
         u_data = np.asarray(u_data, np.float64)
         self.n_snapshots, self.n_x, self.n_u = x_data.shape[1], x_data.shape[0], u_data.shape[0]
@@ -165,7 +185,83 @@ class DMDc:
         modes = scale @ w
         self.modes_re, self.modes_im = np.real(modes).copy(), np.imag(modes).copy()
 
+    # ---- device-resident variant: x_data / u_data are CUDA tensors ------------------------------
+    def _init_device(self, c, x_data, u_data, dt, n_modes, n_iters, seed, omega_x, omega_y):
+        """Same algebra as the host path with every n_x-sized factor left on the GPU: the two randomized SVDs return
+        device tensors, the products that contract or produce an n_x-sized dimension run through ``Context.matmul``
+        (the library's HIP GEMMs), and only snapshot-count x n_modes and n_modes x n_modes matrices visit the host
+        (diag pinv, the complex eigendecomposition of A~).  The dense n_x x n_x operator of ``est_a_til`` is never
+        needed for prediction: A = Re(Phi Lambda Phi^+) = Pc K Pc^T with Pc = [Re Phi | Im Phi] (n_x x 2 n_modes) and
+        a 2 n_modes x 2 n_modes real K, so ``predict_multiple`` runs its recurrence in 2 n_modes dimensions."""
+        import torch
+        dev = torch.device(f"cuda:{c.device}")
+        self._ctx, self._dev = c, dev
+        x = x_data.to(device=dev, dtype=torch.float64)
+        u = torch.as_tensor(u_data, dtype=torch.float64, device=dev)
+        self.n_snapshots, self.n_x, self.n_u = x.shape[1], x.shape[0], u.shape[0]
+        self.n_modes, self.dt_snapshots = n_modes, dt
+        k = n_modes
+        omega = torch.cat([x, u], dim=0)                         # mat_vstack, dmd_rom.rs:66
+        xin, yout = omega[:, :-1], omega[: self.n_x, 1:]         # _X / _Y: strided views, no copies
+        u_til, s_til, vt_til = c.rsvd(xin, k, n_iters, 12, seed=seed, omega=omega_x)
+        u_hat, _s, _v = c.rsvd(yout, k, n_iters, 12, seed=None if seed is None else seed + 1, omega=omega_y)
+        u1, u2 = u_til[: self.n_x], u_til[self.n_x:]
+        up = lambda h: torch.as_tensor(np.ascontiguousarray(h), dtype=torch.float64, device=dev)  # noqa: E731
+        s_inv = _pinv_diag(np.diag(s_til.cpu().numpy().ravel()))
+        v_til = vt_til.t().cpu().numpy()                         # (n_t - 1, k)
+        ytu = c.matmul(yout, u_hat, trans=True).cpu().numpy()    # Y^T U^ (n_t - 1, k)
+        tmp = ytu.T @ v_til @ s_inv                              # eq. 29: U^^T Y V~ S~^-1
+        m1 = c.matmul(u1, u_hat, trans=True).cpu().numpy()       # U~1^T U^ (k, k)
+        self._A = tmp @ m1
+        b_til = c.matmul(u2, up(tmp.T))                          # (n_u, k) = U~2 tmp^T = (tmp U~2^T)^T, eq. 30
+        self._B = c.matmul(u_hat, b_til.t()).contiguous()        # U^ b~  (n_x, n_u), on the device
+        lam, w = np.linalg.eig(self._A)
+        self.lambdas = lam.reshape(-1, 1)
+        scale = c.matmul(yout, up(v_til @ (s_inv @ m1)))         # eq. 36 (n_x, k)
+        self._pc = c.matmul(scale, up(np.hstack([w.real, w.imag]))).contiguous()   # [Re Phi | Im Phi]
+        self.modes_re, self.modes_im = self._pc[:, :k], self._pc[:, k:]
+        # Phi^+ = (Phi^H Phi)^+ Phi^H from the 2k x 2k Gram of Pc.  Columns of Phi are scaled to unit length first
+        # (a Gram matrix squares the condition number; the scaling removes the part of it that is mere column
+        # scaling); modes whose norm is below 1e-8 of the largest are rounding noise of null eigen-directions of A~
+        # (n_modes beyond the rank of the data) and are dropped, as the truncated pseudo-inverse would.
+        gc = c.matmul(self._pc, self._pc, trans=True).cpu().numpy()
+        g = (gc[:k, :k] + gc[k:, k:]) + 1j * (gc[:k, k:] - gc[k:, :k])
+        d = np.sqrt(np.maximum(np.real(np.diag(g)), 0.0))
+        keep = d > 1e-8 * max(d.max(), 1e-300)
+        dinv = np.where(keep, 1.0 / np.where(keep, d, 1.0), 0.0)
+        g_inv = (dinv[:, None] * np.linalg.pinv(g * np.outer(dinv, dinv), hermitian=True)) * dinv[None, :]
+        h = np.diag(lam) @ g_inv                                 # Lambda (Phi^H Phi)^+ ;  A = Re(Phi h Phi^H)
+        self._K = np.block([[h.real, h.imag], [-h.imag, h.real]])
+        self._gc = gc
+        self._pcb = torch.cat([self._pc, self._B], dim=1).contiguous()   # [Pc | B]: one GEMM per prediction batch
+
+    def _est_a_til_device(self):
+        c = self._ctx
+        import torch
+        t = c.matmul(self._pc, torch.as_tensor(self._K, dtype=torch.float64, device=self._dev))
+        return c.matmul(t, self._pc.t())
+
+    def _predict_multiple_device(self, x_0, u_seq):
+        import torch
+        c, dev = self._ctx, self._dev
+        x0 = torch.as_tensor(x_0, dtype=torch.float64, device=dev).reshape(-1, 1)
+        useq = u_seq.detach().cpu().numpy() if _is_torch(u_seq) else np.asarray(u_seq, np.float64)
+        useq = useq.reshape(self.n_u, -1).astype(np.float64)
+        if x0.shape[0] != self.n_x:
+            raise ValueError("x_0 must have n_x rows")           # assert_eq at dmd_rom.rs:199
+        z = c.matmul(self._pc, x0, trans=True).cpu().numpy()     # Pc^T x_0           (2k, 1)
+        bz = c.matmul(self._pc, self._B, trans=True).cpu().numpy()   # Pc^T B         (2k, n_u)
+        n_s = useq.shape[1]
+        coef = np.empty((self._K.shape[0] + self.n_u, n_s))
+        for j in range(n_s):                                     # x_{j+1} = Pc (K Pc^T x_j) + B u_j
+            kz = self._K @ z
+            coef[:, j] = np.concatenate([kz.ravel(), useq[:, j]])
+            z = self._gc @ kz + bz @ useq[:, j:j + 1]
+        return c.matmul(self._pcb, torch.as_tensor(coef, dtype=torch.float64, device=dev))
+
     def est_a_til(self):
+        if self.on_device:
+            return self._est_a_til_device()
         modes = self.modes_re + 1j * self.modes_im
         return np.real(modes @ np.diag(self.lambdas.ravel()) @ np.linalg.pinv(modes))
 
@@ -173,9 +269,14 @@ class DMDc:
         return self._B
 
     def predict(self, x_0, u_input):
+        if self.on_device:
+            u1 = u_input.detach().cpu().numpy() if _is_torch(u_input) else np.asarray(u_input, np.float64)
+            return self._predict_multiple_device(x_0, u1.reshape(self.n_u, 1))
         return self.est_a_til() @ np.asarray(x_0, np.float64).reshape(-1, 1) + self._B @ np.asarray(u_input, np.float64).reshape(-1, 1)
 
     def predict_multiple(self, x_0, u_seq):
+        if self.on_device:
+            return self._predict_multiple_device(x_0, u_seq)
         a = self.est_a_til()
         u_seq = np.asarray(u_seq, np.float64)
         x = np.asarray(x_0, np.float64).reshape(-1, 1)
@@ -184,3 +285,101 @@ class DMDc:
             x = a @ x + self._B @ u_seq[:, j:j + 1]
             out[:, j] = x[:, 0]
         return out
+
+
+# ---- POD with interpolated mode weights ---------------------------------------------------------------
+def _poly_block(x, degree):
+    """build_full_vandermonde (stats_corr.rs:183-207): [x, 1] below degree 2, else [x, x_a x_b (a <= b), 1]."""
+    cols = [x]
+    if degree >= 2:
+        d = x.shape[1]
+        cols += [x[:, a:a + 1] * x[:, b:b + 1] for a in range(d) for b in range(a, d)]
+    return np.hstack(cols + [np.ones((x.shape[0], 1))])
+
+
+def _pinv_reg(m):  # mat_pinv, mat_utils.rs:37-53: every singular value inverted as 1 / (s + 1e-14)
+    u, sv, vt = np.linalg.svd(m, full_matrices=False)
+    return (vt.T * (1.0 / (sv + 1.0e-14))) @ u.T
+
+
+class RbfInterp:
+    """Radial-basis-function interpolant with a polynomial tail (interp_utils.rs:11-160; pyo3 ``PyRbfInterp(kernel_type,
+    kernel_param, dim, poly_degree)``: 1 linear r, 2 multiquadric sqrt(1 + (eps r)^2), 3 cubic r^3, otherwise Gaussian
+    exp(-(eps r)^2)).  Sized by the number of support points (snapshots), so it stays on the host; ``fit`` accepts several
+    right-hand-side columns at once (PodI fits one interpolant per mode weight over the same support points)."""
+
+    def __init__(self, kernel_type, kernel_param, dim, poly_degree):
+        self.kernel_type, self.eps, self.dim, self.poly_degree = int(kernel_type), float(kernel_param), int(dim), int(poly_degree)
+        self.x_known = self.coeffs = None
+
+    def _phi(self, r):
+        if self.kernel_type == 1:
+            return r
+        if self.kernel_type == 2:
+            return np.sqrt(1.0 + (self.eps * r) ** 2)
+        if self.kernel_type == 3:
+            return r * r * r
+        return np.exp(-((r * self.eps) ** 2))
+
+    def _upper(self, x):
+        r = np.sqrt(((x[:, None, :] - self.x_known[None, :, :]) ** 2).sum(axis=2))
+        return np.hstack([self._phi(r), _poly_block(x, self.poly_degree)])
+
+    def fit(self, x_in, y_in):
+        x = np.asarray(x_in, np.float64)
+        y = np.asarray(y_in, np.float64).reshape(x.shape[0], -1)
+        if x.shape[1] != self.dim:
+            raise ValueError("x_in must have `dim` columns")     # assert_eq at interp_utils.rs:133
+        self.x_known = x.copy()
+        upper = self._upper(x)
+        p = upper[:, x.shape[0]:]
+        kp = np.vstack([upper, np.hstack([p.T, np.zeros((p.shape[1], p.shape[1]))])])
+        self.coeffs = _pinv_reg(kp) @ np.vstack([y, np.zeros((p.shape[1], y.shape[1]))])
+
+    def predict(self, x_query):
+        xq = np.asarray(x_query, np.float64)
+        if xq.shape[1] != self.dim:
+            raise ValueError("x_query must have `dim` columns")  # assert_eq at interp_utils.rs:149
+        return self._upper(xq) @ self.coeffs
+
+
+class PodI:
+    """Proper orthogonal decomposition with interpolated mode weights (pod_rom.rs:36-117; pyo3 ``PyPodI(x, t, n_modes)``):
+    x_data is n_snapshots x N, t is n_snapshots x dim.  Modes = right singular vectors of random_svd(x, n_modes, 10, 10) on
+    the GPU; the weights of snapshot i are pinv(modes) x_i^T -- the modes are orthonormal, so that is x_i modes, one HIP
+    GEMM X * modes instead of the reference's N-sized pseudo-inverse; every weight column gets a linear-kernel RBF
+    interpolant over t (host, n_snapshots-sized).  ``predict(t_query)`` returns modes * w(t_query), N x 1, as a numpy
+    array, or as a CUDA tensor when x_data was one."""
+
+    def __init__(self, x_data, t, n_modes, *, seed=None, omega=None, ctx=None):
+        import torch
+        c = ctx or default_context()
+        self._ctx, self.on_device = c, _on_gpu(x_data)
+        dev = torch.device(f"cuda:{c.device}")
+        x = (x_data if self.on_device else torch.as_tensor(np.asarray(x_data, np.float64))).to(device=dev, dtype=torch.float64)
+        t = np.asarray(t.detach().cpu().numpy() if _is_torch(t) else t, np.float64)
+        if t.shape[0] != x.shape[0]:
+            raise ValueError("t and x_data must have the same number of rows")   # assert_eq at pod_rom.rs:38
+        self.n_snapshots, self.n_modes, self.t_abscissa = x.shape[0], int(n_modes), t
+        _u, _s, vt = c.rsvd(x, self.n_modes, 10, 10, seed=seed, omega=omega)     # pod_rom.rs:53-58
+        self._modes = vt.t()                                                     # (N, n_modes), on the device
+        self.mode_weights = c.matmul(x, self._modes).cpu().numpy()               # (n_snapshots, n_modes)
+        self._interp = RbfInterp(1, 0.0, t.shape[1], 1)                          # pod_rom.rs:78-95
+        self._interp.fit(t, self.mode_weights)
+
+    @property
+    def modes(self):
+        return self._modes if self.on_device else self._modes.cpu().numpy()
+
+    def predict(self, t_query):
+        tq = np.asarray(t_query.detach().cpu().numpy() if _is_torch(t_query) else t_query, np.float64)
+        if tq.ndim != 2 or tq.shape[0] != 1:
+            raise ValueError("t_query must be a single row")                     # assert_eq at pod_rom.rs:105
+        return self.predict_many(tq)
+
+    def predict_many(self, t_queries):
+        """Additive: N x n_q fields for n_q query rows at once (one GEMM)."""
+        import torch
+        w = self._interp.predict(np.asarray(t_queries, np.float64)).T           # (n_modes, n_q)
+        out = self._ctx.matmul(self._modes, torch.as_tensor(np.ascontiguousarray(w), dtype=torch.float64, device=self._modes.device))
+        return out if self.on_device else out.cpu().numpy()

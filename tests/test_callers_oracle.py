@@ -33,3 +33,52 @@ def test_active_ss_fit_svd_matches_gram_eigendecomposition():
     lam = np.sort(np.linalg.eigvalsh(g @ g.T / 4000.0))[::-1][:4]
     assert u.shape == (8, 4) and sd.shape == (4, 4)
     assert np.allclose(np.diag(sd) ** 2, lam, rtol=1e-8)
+
+
+# ---- PodI / RbfInterp (pod_rom.rs:36-117, interp_utils.rs:11-160) -----------------------------------
+def test_pod_oracle_on_the_reference_test_data():
+    """test_pod (pod_rom.rs:122-160) only prints its prediction; the properties it relies on are asserted here: the
+    interpolants reproduce the mode weights at the support points (so predict(t_i) is the projection of snapshot i on
+    the modes), and between support points the prediction stays close to the true field's projection."""
+    x, t = co.pod_reference_test_data()
+    m = co.PodIOracle(x, t, 4)
+    assert m.modes.shape == (100, 4) and m.mode_weights.shape == (20, 4)
+    assert np.linalg.norm(m.modes.T @ m.modes - np.eye(4)) < 1e-10
+    for i in (0, 7, 19):
+        assert np.max(np.abs(m.predict(t[i:i + 1]).ravel() - m.modes @ (m.modes.T @ x[i]))) < 1e-10
+    p = m.predict(np.array([[5.2]]))
+    assert p.shape == (100, 1) and np.all(np.isfinite(p))
+    # orthonormal modes: pinv(modes) x^T == modes^T x^T (what the GPU build computes with one GEMM)
+    assert np.max(np.abs(m.mode_weights - x @ m.modes)) < 1e-10
+
+
+@pytest.mark.parametrize("kernel_type,param", [(1, 0.0), (2, 1.0), (3, 0.0), (4, 0.7)])
+@pytest.mark.parametrize("degree", [1, 2])
+def test_rbf_interp_host_helper_matches_the_oracle(kernel_type, param, degree):
+    """corrla_rs_amd.RbfInterp (numpy, n_snapshots-sized host helper of PodI) against the restatement, on the shape of
+    the reference's test_rbf_interp (interp_utils.rs:161-183: 40 samples of sin(x1) + sin(x2), 10 queries)."""
+    from corrla_rs_amd.callers import RbfInterp
+    rng = np.random.default_rng(kernel_type * 10 + degree)
+    x = rng.standard_normal((40, 2))
+    y = (np.sin(x[:, 0]) + np.sin(x[:, 1])).reshape(-1, 1)
+    xq = rng.standard_normal((10, 2))
+    f, fo = RbfInterp(kernel_type, param, 2, degree), co.RbfInterpOracle(kernel_type, param, 2, degree)
+    f.fit(x, y)
+    fo.fit(x, y)
+    assert f.predict(xq).shape == (10, 1)
+    assert np.max(np.abs(f.predict(xq) - fo.predict(xq))) < 1e-7 * max(1.0, np.abs(fo.predict(xq)).max())
+    # several right-hand sides at once == one interpolant per column (PodI's use)
+    y2 = np.hstack([y, np.cos(x[:, :1])])
+    f2 = RbfInterp(kernel_type, param, 2, degree)
+    f2.fit(x, y2)
+    assert np.max(np.abs(f2.predict(xq)[:, :1] - f.predict(xq))) < 1e-6   # the Gaussian kernel matrix is ill-conditioned
+    if kernel_type in (1, 3):      # conditionally positive definite kernels with a polynomial tail interpolate
+        assert np.max(np.abs(f.predict(x) - y)) < 1e-6
+    with pytest.raises(ValueError):
+        f.predict(np.zeros((3, 5)))
+
+
+def test_mat_pinv_comp_is_the_unregularised_pseudo_inverse_for_full_rank():
+    rng = np.random.default_rng(2)
+    m = rng.standard_normal((30, 6)) + 1j * rng.standard_normal((30, 6))
+    assert np.max(np.abs(co.mat_pinv_comp(m) - np.linalg.pinv(m))) < 1e-12

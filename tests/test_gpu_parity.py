@@ -515,6 +515,135 @@ def test_drop_in_pydmdc_class(ctx):
     assert pred.shape[0] == 50 and np.max(np.abs(pred[:, 19] - snaps[:, 20])) < 5e-2
 
 
+# ---- DMDc / POD with the n_x- and N-sized factors resident on the device ---------------------------
+def _lti_snapshots(n_x, n_t, k, n_u, seed):
+    """x_{t+1} = A x_t + B u_t with rank-k dynamics inside an n_x-dimensional state (distinct stable eigenvalues)."""
+    rng = np.random.default_rng(seed)
+    basis = np.linalg.qr(rng.standard_normal((n_x, k)))[0]
+    az = np.diag(np.linspace(0.55, 0.97, k)) + 0.05 * np.triu(rng.standard_normal((k, k)), 1)
+    bz = rng.standard_normal((k, n_u))
+    u = rng.standard_normal((n_u, n_t))
+    z = rng.standard_normal((k, 1))
+    xs = []
+    for t in range(n_t):
+        xs.append((basis @ z)[:, 0])
+        z = az @ z + bz @ u[:, t:t + 1]
+    return np.array(xs).T, u, basis @ az @ basis.T, basis @ bz
+
+
+@pytest.mark.parametrize("n_x,n_t,k,n_u", [(300, 60, 6, 2), (2000, 90, 8, 1), (64, 50, 5, 3)])
+def test_dmdc_device_resident_matches_oracle_and_truth(ctx, torch, n_x, n_t, k, n_u):
+    """CUDA tensors in: factors stay on the device, the predictor is factored (2 n_modes-dimensional recurrence + one
+    GEMM).  Same shared sketches as the oracle -> same operators and the same predictions."""
+    import corrla_rs_amd as cr
+    from oracle import callers_oracle as co
+    x, u, a_true, b_true = _lti_snapshots(n_x, n_t, k, n_u, seed=n_x)
+    rng = np.random.default_rng(5)
+    om_x = rng.standard_normal((min(n_x + n_u, n_t - 1), min(k + 12, min(n_x + n_u, n_t - 1))))
+    om_y = rng.standard_normal((min(n_x, n_t - 1), min(k + 12, min(n_x, n_t - 1))))
+    xd, ud = torch.as_tensor(x, device="cuda"), torch.as_tensor(u, device="cuda")
+    md = cr.DMDc(xd, ud, 1.0, k, 6, omega_x=om_x, omega_y=om_y, ctx=ctx)
+    mh = cr.DMDc(x, u, 1.0, k, 6, omega_x=om_x, omega_y=om_y, ctx=ctx)
+    mo = co.DMDcOracle(x, u, 1.0, k, 6, omega_x=om_x, omega_y=om_y)
+    assert md.on_device and md.est_b_til().is_cuda and md.modes_re.is_cuda and md.modes_re.shape == (n_x, k)
+    sc = np.abs(mo.est_a_til()).max()
+    ad = md.est_a_til()
+    assert ad.is_cuda and ad.shape == (n_x, n_x)
+    assert np.max(np.abs(ad.cpu().numpy() - mo.est_a_til())) < 1e-7 * sc
+    assert np.max(np.abs(mh.est_a_til() - mo.est_a_til())) < 1e-7 * sc
+    assert np.max(np.abs(md.est_b_til().cpu().numpy() - mo.est_b_til())) < 1e-8 * np.abs(mo.est_b_til()).max()
+    assert np.allclose(np.sort_complex(md.lambdas.ravel()), np.sort_complex(mo.lambdas.ravel()), atol=1e-8)
+    # factored multi-step prediction == the dense recurrence of the reference
+    u_seq = u[:, :40]
+    pd_ = md.predict_multiple(xd[:, 0:1], u_seq)
+    assert pd_.is_cuda and pd_.shape == (n_x, 40)
+    po = mo.predict_multiple(x[:, 0:1], u_seq)
+    assert np.max(np.abs(pd_.cpu().numpy() - po)) < 1e-7 * np.abs(po).max()
+    p1 = md.predict(x[:, 3:4], u[:, 3:4])
+    assert p1.shape == (n_x, 1)
+    assert np.max(np.abs(p1.cpu().numpy() - (mo.est_a_til() @ x[:, 3:4] + mo.est_b_til() @ u[:, 3:4]))) < 1e-7 * np.abs(x).max()
+    with pytest.raises(ValueError):
+        md.predict_multiple(x[:5, 0:1], u_seq)
+
+
+def test_dmdc_device_resident_with_more_modes_than_the_data_has(ctx, torch):
+    """n_modes above the rank of the output space: A~ has null eigen-directions whose modes are rounding noise.  The
+    factored predictor must ignore them (as the pseudo-inverse of the modes does) and still reproduce the data."""
+    import corrla_rs_amd as cr
+    from oracle import callers_oracle as co
+    x, u, _a, _b = _lti_snapshots(3000, 120, 10, 3, seed=8)
+    m = cr.DMDc(torch.as_tensor(x, device="cuda"), torch.as_tensor(u, device="cuda"), 1.0, 13, 4, seed=2, ctx=ctx)
+    pred = m.predict_multiple(x[:, 0:1], u[:, :100]).cpu().numpy()
+    assert np.max(np.abs(pred - x[:, 1:101])) < 1e-8 * np.abs(x).max()
+    mo = co.DMDcOracle(x, u, 1.0, 13, 4)
+    assert np.max(np.abs(mo.predict_multiple(x[:, 0:1], u[:, :100]) - x[:, 1:101])) < 1e-8 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("nx,nt", [(50, 40), (500, 40)])
+def test_dmdc_reference_test_device_resident(ctx, torch, nx, nt):
+    """test_dmdc (dmd_rom.rs:233-310) with CUDA tensors: 14 modes, the 20-step prediction within 5e-2."""
+    import corrla_rs_amd as cr
+    from oracle import callers_oracle as co
+    snaps, u = co.dmdc_reference_test_data(nx, nt)
+    m = cr.DMDc(torch.as_tensor(snaps, device="cuda"), torch.as_tensor(u, device="cuda"), 1.0, 14, 40, seed=3, ctx=ctx)
+    assert m.lambdas.shape[0] == 14 and m.est_a_til().shape == (nx, nx) and m.est_b_til().shape == (nx, 1)
+    pred = m.predict_multiple(snaps[:, 0:1], u).cpu().numpy()
+    assert np.max(np.abs(pred[:, 19] - snaps[:, 20])) < 5e-2
+
+
+def test_podi_matches_the_oracle(ctx, torch):
+    """PodI on the reference's test_pod data (pod_rom.rs:122-160): same sketch -> same modes (up to sign), same mode
+    weights (X * modes on the GPU == pinv(modes) x^T), same interpolated prediction; numpy and CUDA inputs."""
+    import corrla_rs_amd as cr
+    from oracle import callers_oracle as co
+    x, t = co.pod_reference_test_data()
+    om = np.random.default_rng(4).standard_normal((20, 14))
+    mo = co.PodIOracle(x, t, 4, omega=om)
+    for xin in (x, torch.as_tensor(x, device="cuda")):
+        m = cr.PodI(xin, t, 4, omega=om, ctx=ctx)
+        modes = m.modes.cpu().numpy() if m.on_device else m.modes
+        assert modes.shape == (100, 4)
+        assert np.linalg.norm(modes @ modes.T - mo.modes @ mo.modes.T) < 1e-8
+        p = m.predict(np.array([[5.2]]))
+        assert (p.is_cuda if m.on_device else isinstance(p, np.ndarray)) and p.shape == (100, 1)
+        pn = p.cpu().numpy() if m.on_device else p
+        assert np.max(np.abs(pn - mo.predict(np.array([[5.2]])))) < 1e-8 * np.abs(mo.predict(np.array([[5.2]]))).max() + 1e-12
+        many = m.predict_many(np.array([[2.0], [5.2], [7.7]]))
+        many = many.cpu().numpy() if m.on_device else many
+        assert many.shape == (100, 3) and np.max(np.abs(many[:, 1:2] - pn)) < 1e-12
+        with pytest.raises(ValueError):
+            m.predict(np.array([[1.0], [2.0]]))
+
+
+def test_drop_in_pypodi_pyrbf_active_ss(ctx):
+    """from corrla_rs import PyPodI, PyRbfInterp, active_ss (lib_math_utils_py.rs:57-86, 178-250)."""
+    from corrla_rs import PyPodI, PyRbfInterp, active_ss
+    from oracle import active_ss_oracle as aso
+    from oracle import callers_oracle as co
+    x, t = co.pod_reference_test_data()
+    pod = PyPodI(x, t, 4)
+    p = pod.predict(np.array([[5.2]]))
+    assert p.shape == (100, 1)
+    # rank-4 reconstruction of a field between two snapshots: close to the projection of the true field on the modes
+    truth = (0.5 * 5.2) * np.exp(-((np.linspace(0, 10, 100) - 5.2) ** 2) / 0.25 ** 2)
+    modes = pod.pod.modes
+    assert np.linalg.norm(p.ravel() - modes @ (modes.T @ truth)) < 0.5 * np.linalg.norm(truth)
+    rb = PyRbfInterp(2, 1.0, 2, 1)
+    xs = np.random.default_rng(0).standard_normal((40, 2))
+    ys = (np.sin(xs[:, 0]) + np.sin(xs[:, 1])).reshape(-1, 1)
+    rb.fit(xs, ys)
+    assert np.max(np.abs(rb.predict(xs) - ys)) < 1e-6
+    # active_ss on the reference's test_active_ss function (active_subspaces.rs:331-394)
+    xa = aso.sample_mv_normal([[0.9, 0.5, 0.5], [0.5, 0.9, 0.5], [0.5, 0.5, 0.9]], 100, np.random.default_rng(7))
+    ya = (0.2 * xa[:, 0] + 0.5 * xa[:, 1] ** 2 + 0.10 * xa[:, 2] * xa[:, 0]).reshape(-1, 1)
+    comps, sv, sensi = active_ss(xa, ya, 2, 14, 2)
+    assert comps.shape == (3, 2) and sv.shape == (3, 2) and sensi.shape == (3,)
+    assert abs(comps[0, 0]) < abs(comps[1, 0]) and sensi[1] > sensi[0] and sensi[1] > sensi[2]
+    go = aso.create_grad_mat(aso.PolyGradientEstimator(xa, ya, 2, 14), xa)
+    lam = np.sort(np.linalg.eigvalsh(go @ go.T / 100.0))[::-1]
+    assert np.allclose(np.diag(sv[:2, :2]), lam[:2], rtol=1e-4)
+
+
 def test_pod_modes_and_active_ss_fit_svd(ctx):
     import corrla_rs_amd as cr
     from oracle import callers_oracle as co
