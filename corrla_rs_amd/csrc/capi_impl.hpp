@@ -150,16 +150,17 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
   Skinny<T> ut = dev.template alloc_skinny<T>(ta.mt, k);
   Skinny<T> vtall = dev.template alloc_skinny<T>(ta.nt, k);
   T* s_dev = dev.template alloc_scalar<T>((int)k);
-  drv.random_svd_tall(ta, k, l, n_iter, ro, ut, s_dev, vtall);
-  // random_svd.rs:96-109: tall -> (U, S, V^T); fat -> (V, S, U^T) of the transposed problem
-  if (!fat) {
-    dev.copy_out(ut, k, u, ldu, /*transpose=*/false, host_ptrs);
-    dev.copy_out(vtall, k, vt, ldvt, /*transpose=*/true, host_ptrs);
-  } else {
-    dev.copy_out(vtall, k, u, ldu, false, host_ptrs);
-    dev.copy_out(ut, k, vt, ldvt, true, host_ptrs);
-  }
-  dev.copy_values_out(s_dev, k, s, host_ptrs);
+  drv.random_svd_tall(ta, k, l, n_iter, ro, ut, s_dev, vtall, [&] {
+    // random_svd.rs:96-109: tall -> (U, S, V^T); fat -> (V, S, U^T) of the transposed problem
+    if (!fat) {
+      dev.copy_out(ut, k, u, ldu, /*transpose=*/false, host_ptrs);
+      dev.copy_out(vtall, k, vt, ldvt, /*transpose=*/true, host_ptrs);
+    } else {
+      dev.copy_out(vtall, k, u, ldu, false, host_ptrs);
+      dev.copy_out(ut, k, vt, ldvt, true, host_ptrs);
+    }
+    dev.copy_values_out(s_dev, k, s, host_ptrs);
+  });
   dev.end_call();
   drv.tm.sketch_kernel_ms = dev.event_elapsed_ms(0, 1);
   if (tm_out) *tm_out = drv.tm;
@@ -222,14 +223,15 @@ inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n
   Skinny<T> ut = dev.template alloc_skinny<T>(tc.mt, k);
   Skinny<T> vtall = dev.template alloc_skinny<T>(tc.nt, k);
   T* s_dev = dev.template alloc_scalar<T>((int)k);
-  drv.random_svd_tall(tc, k, l, n_iter, ro, ut, s_dev, vtall);
-  // components_ = vr = V^T (k x n_dim)   pca_rsvd.rs:70-71
-  if (!fat)
-    dev.copy_out(vtall, k, comps, ldc, /*transpose=*/true, host_ptrs);
-  else
-    dev.copy_out(ut, k, comps, ldc, true, host_ptrs);
-  dev.copy_values_out(s_dev, k, s, host_ptrs);
-  dev.copy_values_out(mu.p, n, means, host_ptrs);
+  drv.random_svd_tall(tc, k, l, n_iter, ro, ut, s_dev, vtall, [&] {
+    // components_ = vr = V^T (k x n_dim)   pca_rsvd.rs:70-71
+    if (!fat)
+      dev.copy_out(vtall, k, comps, ldc, /*transpose=*/true, host_ptrs);
+    else
+      dev.copy_out(ut, k, comps, ldc, true, host_ptrs);
+    dev.copy_values_out(s_dev, k, s, host_ptrs);
+    dev.copy_values_out(mu.p, n, means, host_ptrs);
+  });
   dev.end_call();
   if (tm_out) *tm_out = drv.tm;
 }

@@ -12,6 +12,7 @@
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "small_linalg.hpp"
@@ -464,8 +465,11 @@ struct RsvdDriver {
 
   // ---- random_svd, random_svd.rs:63-110, on the already-tall view ------------------------
   // u_tall: mt x k, v_tall: nt x k (both skinny, allocated by the caller), s_dev: k values (device).
+  // emit (optional): enqueues the caller's output copies.  It runs BEFORE the status records of the optimistic run are
+  // read, so the copies follow the last kernel without a host round trip in between; if the run has to be repeated
+  // it runs again and overwrites them.
   void random_svd_tall(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
-                       T* s_dev, Skinny<T>& v_tall) {
+                       T* s_dev, Skinny<T>& v_tall, const std::function<void()>& emit = {}) {
     if (dev.template device_chol_fits<T>(l) || dev.template device_chol_blocked_fits<T>(l)) {
       // Optimistic run: every Cholesky-QR status record is checked once, after the last kernel is enqueued
       // (no host synchronisation inside the call).  A record that is not clean (rank deficiency, zero or
@@ -482,10 +486,12 @@ struct RsvdDriver {
         throw;
       }
       defer_status_ = false;
+      if (emit) emit();
       if (pending_clean()) return;
       tm = saved;
     }
     random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
+    if (emit) emit();
   }
 
   bool pending_clean() {
