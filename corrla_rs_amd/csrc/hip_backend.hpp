@@ -233,7 +233,9 @@ class HipDev {
   // ---- collectives (RCCL over xGMI, on the compute stream) ---------------------------------
   template <class T>
   void allreduce(T* p, size_t count) {
-    if (comm_size <= 1) return;
+    // CORRLA_FORCE_ALLREDUCE=1: issue the collective on a one-rank communicator too (an identity), so that a 1-GPU
+    // box exercises the very RCCL calls -- datatype, count, in-place buffer, stream -- the N > 1 ranks make
+    if (comm_size <= 1 && !(comm && env_int("CORRLA_FORCE_ALLREDUCE", 0))) return;
     if (!comm) throw Error(ST_ECOMM, "communicator not initialised");
     CORRLA_NCCL(ncclAllReduce(p, p, count, NcclType<T>::v, ncclSum, comm, stream));
   }

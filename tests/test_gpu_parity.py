@@ -660,7 +660,7 @@ def test_pod_modes_and_active_ss_fit_svd(ctx):
     assert np.linalg.norm(ug @ ug.T - uo @ uo.T) < 1e-7
 
 
-def test_sharded_entry_point_with_world_size_1_rccl(torch):
+def test_sharded_entry_point_with_world_size_1_rccl(torch, monkeypatch):
     """The row-sharded entry point with a real RCCL communicator of one rank equals the plain entry point
     (the N > 1 exchange logic is covered by tests/test_sharded_gloo.py through the same driver)."""
     import corrla_rs_amd as cr
@@ -672,6 +672,14 @@ def test_sharded_entry_point_with_world_size_1_rccl(torch):
     u1, s1, vt1 = c.rsvd_sharded(a, 16, 4, 10, omega=om)
     u0, s0, vt0 = c.rsvd(a, 16, 4, 10, omega=om)
     assert torch.equal(s0, s1) and torch.equal(u0, u1) and torch.equal(vt0, vt1)
+    # the same with every all-reduce actually issued to RCCL (identity on one rank): the calls the N > 1 ranks make
+    monkeypatch.setenv("CORRLA_FORCE_ALLREDUCE", "1")
+    u2, s2, vt2 = c.rsvd_sharded(a, 16, 4, 10, omega=om)
+    ad = a.double()
+    u3, s3, vt3 = c.rsvd_sharded(ad, 16, 4, 10, omega=om.astype(np.float64))
+    monkeypatch.delenv("CORRLA_FORCE_ALLREDUCE")
+    assert torch.equal(s0, s2) and torch.equal(u0, u2) and torch.equal(vt0, vt2)
+    assert torch.allclose(s3.float(), s0, rtol=1e-4)
     c.close()
 
 
