@@ -16,6 +16,7 @@ CONFIGS = {
     "C3q2": (65536, 4096, torch.float64, 256, 2, 10),
     "C3": (65536, 4096, torch.float64, 256, 10, 10),
     "C4shard": (1_250_000, 512, torch.float32, 64, 2, 10),
+    "C4full": (10_000_000, 512, torch.float32, 64, 2, 10),     # the whole 10^7 x 512 matrix (20.5 GB) on ONE GPU
     "C5": (1_000_000, 64, torch.float64, 32, 8, 10),
     "C2col": (16384, 16384, torch.float32, 128, 2, 10),
 }
