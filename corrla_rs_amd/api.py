@@ -87,6 +87,16 @@ class Context:
         return {f: getattr(t, f) for f, _ in t._fields_ if f != "reserved"}
 
     # ---- helpers -----------------------------------------------------------------------
+    @staticmethod
+    def _qr_flag(qr):
+        """qr=None / "cholesky": the default CholeskyQR2; "householder": Householder TSQR with an explicit thin Q
+        (CORRLA_QR_HOUSEHOLDER; the reference's `qr().compute_thin_q()` as written, random_svd.rs:38,57)."""
+        if qr in (None, "cholesky"):
+            return 0
+        if qr == "householder":
+            return L.QR_HOUSEHOLDER
+        raise ValueError("qr must be None, 'cholesky' or 'householder'")
+
     def _opts(self, seed, omega, nt, l, dtype, on_device, extra_flags=0):
         if seed is None and omega is None and not extra_flags:
             return None, None
@@ -115,10 +125,10 @@ class Context:
         return o, keep
 
     # ---- random_svd ----------------------------------------------------------------------
-    def rsvd(self, a_mat, n_rank, n_iters, n_oversamples, *, seed=None, omega=None):
+    def rsvd(self, a_mat, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, qr=None):
         n_rank, n_iters, n_oversamples = int(n_rank), int(n_iters), int(n_oversamples)
         if _is_torch(a_mat) and a_mat.is_cuda:
-            return self._rsvd_torch(a_mat, n_rank, n_iters, n_oversamples, seed, omega)
+            return self._rsvd_torch(a_mat, n_rank, n_iters, n_oversamples, seed, omega, qr=qr)
         a = np.asarray(a_mat.detach().cpu().numpy() if _is_torch(a_mat) else a_mat)
         if a.ndim != 2:
             raise ValueError("a_mat must be 2-D")
@@ -134,7 +144,7 @@ class Context:
         k = n_rank
         nt = min(m, n)
         l = min(k + max(n_oversamples, 0), nt)
-        o, keep = self._opts(seed, omega, nt, l, a.dtype, False)
+        o, keep = self._opts(seed, omega, nt, l, a.dtype, False, self._qr_flag(qr))
         kk = max(k, 1)
         u = np.empty((m, kk), dtype=a.dtype, order="F")
         s = np.empty((kk, 1), dtype=a.dtype, order="F")
@@ -145,7 +155,7 @@ class Context:
         del keep
         return u, s, vt
 
-    def _rsvd_torch(self, a, k, q, p, seed, omega, sharded=False):
+    def _rsvd_torch(self, a, k, q, p, seed, omega, sharded=False, qr=None):
         import torch
         if a.dim() != 2:
             raise ValueError("a_mat must be 2-D")
@@ -162,7 +172,7 @@ class Context:
         suf = "f32" if a.dtype == torch.float32 else "f64"
         nt = n if sharded else min(m, n)
         l = min(k + max(p, 0), nt)
-        o, keep = self._opts(seed, omega, nt, l, a.dtype, True)
+        o, keep = self._opts(seed, omega, nt, l, a.dtype, True, self._qr_flag(qr))
         kk = max(k, 1)
         dev = a.device
         u = torch.empty((kk, m), dtype=a.dtype, device=dev).t()     # (m, k) column-major
@@ -269,7 +279,7 @@ class Context:
         return g.T, nreg.value
 
     # ---- power_iter ----------------------------------------------------------------------
-    def power_iter(self, a_mat, omega_rank, n_iter, *, seed=None, omega=None):
+    def power_iter(self, a_mat, omega_rank, n_iter, *, seed=None, omega=None, qr=None):
         a = np.asarray(a_mat)
         if a.ndim != 2:
             raise ValueError("a_mat must be 2-D")
@@ -279,7 +289,7 @@ class Context:
         w = int(omega_rank)
         suf = "f32" if a.dtype == np.float32 else "f64"
         rs, cs = a.strides[0] // a.itemsize, a.strides[1] // a.itemsize
-        o, keep = self._opts(seed, omega, n, w, a.dtype, False)
+        o, keep = self._opts(seed, omega, n, w, a.dtype, False, self._qr_flag(qr))
         q = np.empty((m, max(w, 1)), dtype=a.dtype, order="F")
         fn = getattr(self._lib, "corrla_power_iter_" + suf)
         L.check(fn(self._h, a.ctypes.data, m, n, rs, cs, w, int(n_iter), C.byref(o) if o is not None else None,
@@ -346,21 +356,21 @@ def default_context():
         return _default
 
 
-def rsvd(a_mat, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, ctx=None):
+def rsvd(a_mat, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, ctx=None, qr=None):
     """corrla_rs.rsvd(a_mat, n_rank, n_iters, n_oversamples) -> (U (m,k), S (k,1), Vt (k,n)).
-    src/lib_math_utils_py.rs:21-36."""
-    return (ctx or default_context()).rsvd(a_mat, n_rank, n_iters, n_oversamples, seed=seed, omega=omega)
+    src/lib_math_utils_py.rs:21-36.  qr="householder" selects the Householder TSQR thin-Q (default: CholeskyQR2)."""
+    return (ctx or default_context()).rsvd(a_mat, n_rank, n_iters, n_oversamples, seed=seed, omega=omega, qr=qr)
 
 
-def random_svd(a_mat, omega_rank, n_iter, n_oversamples, *, seed=None, omega=None, ctx=None):
+def random_svd(a_mat, omega_rank, n_iter, n_oversamples, *, seed=None, omega=None, ctx=None, qr=None):
     """random_svd(a_mat, omega_rank, n_iter, n_oversamples), random_svd.rs:63-66."""
-    return rsvd(a_mat, omega_rank, n_iter, n_oversamples, seed=seed, omega=omega, ctx=ctx)
+    return rsvd(a_mat, omega_rank, n_iter, n_oversamples, seed=seed, omega=omega, ctx=ctx, qr=qr)
 
 
-def power_iter(a_mat, omega_rank, n_iter, *, seed=None, omega=None, ctx=None):
+def power_iter(a_mat, omega_rank, n_iter, *, seed=None, omega=None, ctx=None, qr=None):
     """power_iter(a_mat, omega_rank, n_iter) -> Q (m, omega_rank), random_svd.rs:15-18.  `omega_rank` is
     the already-oversampled sketch width."""
-    return (ctx or default_context()).power_iter(a_mat, omega_rank, n_iter, seed=seed, omega=omega)
+    return (ctx or default_context()).power_iter(a_mat, omega_rank, n_iter, seed=seed, omega=omega, qr=qr)
 
 
 def rpca(a_mat, n_rank, n_iters=None, n_oversamples=None, *, seed=None, omega=None, ctx=None):

@@ -36,6 +36,8 @@ inline corrla_status guarded(F&& f) {
 
 inline RunOpts parse_opts(const corrla_opts* o, bool dev_ptrs) {
   RunOpts r;
+  const char* qr_env = std::getenv("CORRLA_QR");
+  r.qr_householder = qr_env && std::strcmp(qr_env, "householder") == 0;
   if (!o) return r;
   if (o->struct_size != sizeof(corrla_opts)) throw Error(ST_EINVAL, "corrla_opts.struct_size mismatch");
   r.seed = o->seed ? o->seed : r.seed;
@@ -46,6 +48,7 @@ inline RunOpts parse_opts(const corrla_opts* o, bool dev_ptrs) {
   if ((o->flags & CORRLA_PCA_CENTER_FUSED) && (o->flags & CORRLA_PCA_CENTER_COPY))
     throw Error(ST_EINVAL, "CORRLA_PCA_CENTER_FUSED and CORRLA_PCA_CENTER_COPY are mutually exclusive");
   r.pca_center = (o->flags & CORRLA_PCA_CENTER_FUSED) ? 1 : ((o->flags & CORRLA_PCA_CENTER_COPY) ? 2 : 0);
+  r.qr_householder = r.qr_householder || (o->flags & CORRLA_QR_HOUSEHOLDER) != 0;
   return r;
 }
 

@@ -97,6 +97,7 @@ struct RunOpts {
   bool omega_on_device = false;
   bool sharded = false;  // rows of A are sharded over the communicator
   int pca_center = 0;    // 0 default, 1 fused, 2 centred copy (corrla_pca_* only)
+  bool qr_householder = false;  // thin-Q by Householder TSQR instead of CholeskyQR2 (CORRLA_QR_HOUSEHOLDER)
 };
 
 struct Timings {
@@ -126,6 +127,7 @@ struct RsvdDriver {
   Dev& dev;
   Timings tm;
   bool profile_phases;  // synchronise at phase boundaries to attribute time
+  bool qr_householder = false;  // set from RunOpts by the entry points (random_svd_tall, power_iter)
   static constexpr const T* kNone = nullptr;
 
   explicit RsvdDriver(Dev& d, bool profile = false) : dev(d), profile_phases(profile) {}
@@ -186,6 +188,14 @@ struct RsvdDriver {
 
   int64_t orthonormalize(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough = false) {
     const int64_t l = y.cols;
+    if (qr_householder && !sharded && y.rows >= l && dev.template householder_fits<T>(l)) {
+      // random_svd.rs:38,57 as written: Householder QR, explicit thin Q (orthonormal for any rank of y)
+      PhaseTimer qt0;
+      dev.householder_thin_q(y, tmp);
+      ++tm.qr_passes;
+      phase(tm.qr_gram_ms, qt0);
+      return l;
+    }
     int64_t r = orthonormalize_core(y, tmp, sharded, rough);
     // A Householder thin-Q (random_svd.rs:38,57) is orthonormal whatever the rank of its input: the directions a
     // rank-deficient sketch does not determine are an arbitrary orthonormal completion.  Reproduce that instead of
@@ -424,6 +434,7 @@ struct RsvdDriver {
   // ---- power_iter, random_svd.rs:15-59 -------------------------------------------------
   // Leaves the orthonormal basis in `y` (mt x l) and returns its numerical rank.
   int64_t power_iter(const TallA<T>& a, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& y, Skinny<T>& y2) {
+    qr_householder = o.qr_householder;
     PhaseTimer pt;
     Skinny<T> om = dev.template alloc_skinny<T>(a.nt, l);
     if (o.omega) {
@@ -470,7 +481,11 @@ struct RsvdDriver {
   // it runs again and overwrites them.
   void random_svd_tall(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
                        T* s_dev, Skinny<T>& v_tall, const std::function<void()>& emit = {}) {
-    if (dev.template device_chol_fits<T>(l) || dev.template device_chol_blocked_fits<T>(l)) {
+    qr_householder = o.qr_householder;
+    // Householder mode has no status records to defer: the body runs with the host in the loop, which also lets it
+    // complete the null vectors of an exactly singular core (see random_svd_tall_body)
+    const bool hh = qr_householder && !o.sharded && dev.template householder_fits<T>(l);
+    if (!hh && (dev.template device_chol_fits<T>(l) || dev.template device_chol_blocked_fits<T>(l))) {
       // Optimistic run: every Cholesky-QR status record is checked once, after the last kernel is enqueued
       // (no host synchronisation inside the call).  A record that is not clean (rank deficiency, zero or
       // non-finite input, ...) repeats the computation with the host in the loop.

@@ -16,6 +16,7 @@
 
 #include "driver.hpp"
 #include "hip_kernels.hpp"
+#include "tsqr_kernels.hpp"
 
 namespace corrla {
 
@@ -78,6 +79,8 @@ class HipDev {
     set_jacobi_attrs<double>();
     set_ring_attrs<float, 20>();
     set_ring_attrs<double, 18>();
+    set_tsqr_attrs<float>();
+    set_tsqr_attrs<double>();
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<float>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<double>,
@@ -386,6 +389,62 @@ class HipDev {
     memset_zero(m_out.p, (size_t)m_out.ld * m_out.cols_alloc * sizeof(T));
     hipLaunchKernelGGL((k::series_combine_kernel<T>), grid, dim3(64), 0, stream, (const T*)g.p, (const T*)e2.p,
                        (const T*)e3.p, g.ld, (int)r, m_out.p, m_out.ld);
+    CORRLA_HIP(hipGetLastError());
+  }
+
+  template <class T>
+  void set_tsqr_attrs() {
+    const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_leaf_factor_kernel<T>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_tree_factor_kernel<T>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_tree_apply_kernel<T>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_leaf_apply_kernel<T>, attr, 160 * 1024));
+  }
+
+  // ---- Householder TSQR with explicit thin Q (tsqr_kernels.hpp) -------------------------------------------
+  // one 2 l x l panel must fit in LDS: l <= 138 (f32) / 97 (f64)
+  template <class T>
+  bool householder_fits(int64_t l) const {
+    return l >= 1 && l <= 4096 && k::hh_lds_bytes((int)(2 * l), (int)l, sizeof(T)) <= (size_t)160 * 1024 &&
+           2 * l <= 64 * k::kHhMaxRowsPerLane;
+  }
+  // y (m x l, m >= l) <- thin Q of its Householder QR; tmp (same shape) receives the leaf reflectors
+  template <class T>
+  void householder_thin_q(Skinny<T>& y, Skinny<T>& tmp) {
+    const int64_t m = y.rows;
+    const int l = (int)y.cols;
+    if (m < l) throw Error(ST_EINVAL, "householder_thin_q: fewer rows than columns");
+    if (!householder_fits<T>(l)) throw Error(ST_EINVAL, "householder_thin_q: panel does not fit in LDS");
+    const int64_t br = 2 * (int64_t)l;
+    const int64_t nleaf64 = m <= br ? 1 : (m + br - 1) / br;
+    if (nleaf64 > 0x3fffffff) throw Error(ST_EINVAL, "householder_thin_q: too many panels");
+    const int nleaf = (int)nleaf64;
+    const int max_rows = (int)std::min<int64_t>(m, br);
+    const size_t lds = k::hh_lds_bytes(max_rows, l, sizeof(T));
+    std::vector<int> n_at{nleaf};
+    while (n_at.back() > 1) n_at.push_back((n_at.back() + 1) / 2);
+    const int levels = (int)n_at.size() - 1;
+    const size_t ll = (size_t)l * l;
+    std::vector<T*> rbuf(levels + 1), cbuf(levels + 1), taub(levels + 1), vbuf(levels + 1, nullptr);
+    for (int k_ = 0; k_ <= levels; ++k_) {
+      rbuf[k_] = (T*)alloc_bytes(ll * n_at[k_] * sizeof(T));
+      cbuf[k_] = (T*)alloc_bytes(ll * n_at[k_] * sizeof(T));
+      taub[k_] = (T*)alloc_bytes((size_t)l * n_at[k_] * sizeof(T));
+      if (k_ >= 1) vbuf[k_] = (T*)alloc_bytes(2 * ll * n_at[k_] * sizeof(T));
+    }
+    hipLaunchKernelGGL((k::hh_leaf_factor_kernel<T>), dim3((unsigned)nleaf), dim3(k::kHhThreads), lds, stream, (const T*)y.p, y.ld,
+                       m, l, nleaf, tmp.p, tmp.ld, taub[0], rbuf[0]);
+    const size_t lds_tree = k::hh_lds_bytes(2 * l, l, sizeof(T));
+    for (int k_ = 1; k_ <= levels; ++k_)
+      hipLaunchKernelGGL((k::hh_tree_factor_kernel<T>), dim3((unsigned)n_at[k_]), dim3(k::kHhThreads), lds_tree, stream,
+                         (const T*)rbuf[k_ - 1], n_at[k_ - 1], l, vbuf[k_], taub[k_], rbuf[k_]);
+    for (int k_ = levels; k_ >= 1; --k_)
+      hipLaunchKernelGGL((k::hh_tree_apply_kernel<T>), dim3((unsigned)n_at[k_]), dim3(k::kHhThreads), lds_tree, stream,
+                         (const T*)(k_ == levels ? nullptr : cbuf[k_]), (const T*)vbuf[k_], (const T*)taub[k_], n_at[k_ - 1], l,
+                         cbuf[k_ - 1]);
+    hipLaunchKernelGGL((k::hh_leaf_apply_kernel<T>), dim3((unsigned)nleaf), dim3(k::kHhThreads), lds, stream,
+                       (const T*)(levels == 0 ? nullptr : cbuf[0]), (const T*)tmp.p, tmp.ld, (const T*)taub[0], m, l, nleaf, y.p,
+                       y.ld);
     CORRLA_HIP(hipGetLastError());
   }
 

@@ -63,6 +63,12 @@ typedef enum corrla_status {
  * Default (neither flag): FUSED for f64, COPY for f32 (the fused form cancels digits when |mean| >> spread). */
 #define CORRLA_PCA_CENTER_FUSED 0x2u
 #define CORRLA_PCA_CENTER_COPY 0x4u
+/* Thin-Q of the sketch (`y_mat.qr().compute_thin_q()`, random_svd.rs:38,57) by Householder TSQR with an explicit Q
+ * (row panels reduced in LDS, pairwise tree over the R factors, reflectors applied in reverse) instead of the default
+ * CholeskyQR2.  Available for l = min(rank + n_oversamples, n) <= 138 (f32) / 97 (f64) on unsharded calls; wider
+ * sketches and the row-sharded entry points use the default path.  The environment variable CORRLA_QR=householder
+ * sets it for every call. */
+#define CORRLA_QR_HOUSEHOLDER 0x8u
 
 /*
  * Options block.  Zero-initialise, set struct_size = sizeof(corrla_opts).  NULL opts == defaults.

@@ -187,6 +187,138 @@ class EmuDev {
   bool device_chol_blocked_fits(int64_t l) const {
     return l > 8 && l <= 276 && !std::getenv("CORRLA_EMU_NO_DEVICE_CHOL");
   }
+  // ---- Householder TSQR with explicit thin Q: the same panel partition, pairwise tree and reverse application as
+  // csrc/tsqr_kernels.hpp / HipDev::householder_thin_q, written with plain loops --------------------------------
+  template <class T>
+  bool householder_fits(int64_t l) const {
+    return l >= 1 && (size_t)((2 * l + 3) / 4 * 4) * (size_t)l * sizeof(T) + 64 <= (size_t)160 * 1024 && 2 * l <= 320;
+  }
+  template <class T>
+  static void hh_factor_panel(std::vector<T>& P, int rows, int l, T* tau) {  // P column-major rows x l
+    for (int j = 0; j < l; ++j) {
+      T* cj = P.data() + (size_t)j * rows;
+      T sigma = 0;
+      for (int r = j + 1; r < rows; ++r) sigma += cj[r] * cj[r];
+      const T alpha = cj[j];
+      T t = 0, beta = alpha, scale = 0;
+      if (sigma > (T)0) {
+        beta = -std::copysign(std::sqrt(alpha * alpha + sigma), alpha);
+        t = (beta - alpha) / beta;
+        scale = (T)1 / (alpha - beta);
+      }
+      for (int r = j + 1; r < rows; ++r) cj[r] *= scale;
+      cj[j] = beta;
+      tau[j] = t;
+      for (int c = j + 1; c < l; ++c) {
+        T* cc = P.data() + (size_t)c * rows;
+        T d = cc[j];
+        for (int r = j + 1; r < rows; ++r) d += cj[r] * cc[r];
+        const T w = t * d;
+        cc[j] -= w;
+        for (int r = j + 1; r < rows; ++r) cc[r] -= w * cj[r];
+      }
+    }
+  }
+  template <class T>
+  static void hh_apply_panel(std::vector<T>& P, int rows, int l, const T* V, int64_t ldv, const T* tau) {
+    for (int j = l - 1; j >= 0; --j) {
+      if (tau[j] == (T)0) continue;
+      const T* v = V + (int64_t)j * ldv;
+      for (int c = 0; c < l; ++c) {
+        T* cc = P.data() + (size_t)c * rows;
+        T d = cc[j];
+        for (int r = j + 1; r < rows; ++r) d += v[r] * cc[r];
+        const T w = tau[j] * d;
+        cc[j] -= w;
+        for (int r = j + 1; r < rows; ++r) cc[r] -= w * v[r];
+      }
+    }
+  }
+  template <class T>
+  void householder_thin_q(Skinny<T>& y, Skinny<T>& tmp) {
+    const int64_t m = y.rows;
+    const int l = (int)y.cols;
+    if (m < l) throw Error(ST_EINVAL, "householder_thin_q: fewer rows than columns");
+    const int64_t br = 2 * (int64_t)l;
+    const int nleaf = (int)(m <= br ? 1 : (m + br - 1) / br);
+    auto row0 = [&](int i) { return (m * (int64_t)i) / nleaf; };
+    std::vector<int> n_at{nleaf};
+    while (n_at.back() > 1) n_at.push_back((n_at.back() + 1) / 2);
+    const int levels = (int)n_at.size() - 1;
+    const size_t ll = (size_t)l * l;
+    std::vector<std::vector<T>> rbuf(levels + 1), cbuf(levels + 1), taub(levels + 1), vbuf(levels + 1);
+    for (int k = 0; k <= levels; ++k) {
+      rbuf[k].assign(ll * n_at[k], 0);
+      cbuf[k].assign(ll * n_at[k], 0);
+      taub[k].assign((size_t)l * n_at[k], 0);
+      if (k >= 1) vbuf[k].assign(2 * ll * n_at[k], 0);
+    }
+    for (int i = 0; i < nleaf; ++i) {  // leaves (up)
+      const int64_t r0 = row0(i);
+      const int rows = (int)(row0(i + 1) - r0);
+      std::vector<T> P((size_t)rows * l);
+      for (int c = 0; c < l; ++c)
+        for (int r = 0; r < rows; ++r) P[(size_t)c * rows + r] = y.p[(int64_t)c * y.ld + r0 + r];
+      hh_factor_panel(P, rows, l, taub[0].data() + (size_t)i * l);
+      for (int c = 0; c < l; ++c)
+        for (int r = 0; r < rows; ++r) {
+          tmp.p[(int64_t)c * tmp.ld + r0 + r] = P[(size_t)c * rows + r];
+          if (r < l) rbuf[0][(size_t)i * ll + (size_t)c * l + r] = r <= c ? P[(size_t)c * rows + r] : (T)0;
+        }
+    }
+    for (int k = 1; k <= levels; ++k)  // tree (up)
+      for (int t = 0; t < n_at[k]; ++t) {
+        const int a = 2 * t, b = 2 * t + 1;
+        if (b >= n_at[k - 1]) {
+          std::copy(rbuf[k - 1].begin() + (size_t)a * ll, rbuf[k - 1].begin() + (size_t)(a + 1) * ll, rbuf[k].begin() + (size_t)t * ll);
+          continue;  // tau stays 0
+        }
+        const int rows = 2 * l;
+        std::vector<T> P((size_t)rows * l);
+        for (int c = 0; c < l; ++c)
+          for (int r = 0; r < l; ++r) {
+            P[(size_t)c * rows + r] = rbuf[k - 1][(size_t)a * ll + (size_t)c * l + r];
+            P[(size_t)c * rows + l + r] = rbuf[k - 1][(size_t)b * ll + (size_t)c * l + r];
+          }
+        hh_factor_panel(P, rows, l, taub[k].data() + (size_t)t * l);
+        std::copy(P.begin(), P.end(), vbuf[k].begin() + (size_t)t * 2 * ll);
+        for (int c = 0; c < l; ++c)
+          for (int r = 0; r < l; ++r) rbuf[k][(size_t)t * ll + (size_t)c * l + r] = r <= c ? P[(size_t)c * rows + r] : (T)0;
+      }
+    auto coeff = [&](int k, int t, int r, int c) -> T {  // root: identity
+      return k == levels ? (r == c ? (T)1 : (T)0) : cbuf[k][(size_t)t * ll + (size_t)c * l + r];
+    };
+    for (int k = levels; k >= 1; --k)  // tree (down)
+      for (int t = 0; t < n_at[k]; ++t) {
+        const int a = 2 * t, b = 2 * t + 1;
+        if (b >= n_at[k - 1]) {
+          for (int c = 0; c < l; ++c)
+            for (int r = 0; r < l; ++r) cbuf[k - 1][(size_t)a * ll + (size_t)c * l + r] = coeff(k, t, r, c);
+          continue;
+        }
+        const int rows = 2 * l;
+        std::vector<T> P((size_t)rows * l, (T)0);
+        for (int c = 0; c < l; ++c)
+          for (int r = 0; r < l; ++r) P[(size_t)c * rows + r] = coeff(k, t, r, c);
+        hh_apply_panel(P, rows, l, vbuf[k].data() + (size_t)t * 2 * ll, (int64_t)rows, taub[k].data() + (size_t)t * l);
+        for (int c = 0; c < l; ++c)
+          for (int r = 0; r < l; ++r) {
+            cbuf[k - 1][(size_t)a * ll + (size_t)c * l + r] = P[(size_t)c * rows + r];
+            cbuf[k - 1][(size_t)b * ll + (size_t)c * l + r] = P[(size_t)c * rows + l + r];
+          }
+      }
+    for (int i = 0; i < nleaf; ++i) {  // leaves (down)
+      const int64_t r0 = row0(i);
+      const int rows = (int)(row0(i + 1) - r0);
+      std::vector<T> P((size_t)rows * l, (T)0);
+      for (int c = 0; c < l; ++c)
+        for (int r = 0; r < l && r < rows; ++r) P[(size_t)c * rows + r] = coeff(0, i, r, c);
+      hh_apply_panel(P, rows, l, tmp.p + r0, tmp.ld, taub[0].data() + (size_t)i * l);
+      for (int c = 0; c < l; ++c)
+        for (int r = 0; r < rows; ++r) y.p[(int64_t)c * y.ld + r0 + r] = P[(size_t)c * rows + r];
+    }
+  }
+
   template <class T>
   void copy_block(const Skinny<T>& src, int64_t r0, int64_t c0, int64_t rows, int64_t cols, Skinny<T>& dst, int64_t dr0,
                   int64_t dc0) {

@@ -24,12 +24,13 @@ def emu():
     return _emu
 
 
-def _opts(omega, nt, l, dtype, seed=None):
-    if omega is None and seed is None:
+def _opts(omega, nt, l, dtype, seed=None, flags=0):
+    if omega is None and seed is None and not flags:
         return None, None
     o = L.Opts()
     o.struct_size = C.sizeof(L.Opts)
     o.seed = int(seed or 0)
+    o.flags = int(flags)
     keep = None
     if omega is not None:
         keep = np.asfortranarray(np.asarray(omega, dtype=dtype))
@@ -39,7 +40,7 @@ def _opts(omega, nt, l, dtype, seed=None):
     return o, keep
 
 
-def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=False):
+def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=False, qr=None):
     e = emu()
     a = np.asarray(a)
     dtype = a.dtype
@@ -48,7 +49,7 @@ def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=Fal
     rs, cs = a.strides[0] // a.itemsize, a.strides[1] // a.itemsize
     nt = n if sharded else min(m, n)
     l = min(k + p, nt)
-    o, keep = _opts(omega, nt, l, dtype, seed)
+    o, keep = _opts(omega, nt, l, dtype, seed, L.QR_HOUSEHOLDER if qr == "householder" else 0)
     u = np.empty((m, max(k, 1)), dtype=dtype, order="F")
     s = np.empty((max(k, 1), 1), dtype=dtype, order="F")
     vt = np.empty((max(k, 1), n), dtype=dtype, order="F")
@@ -71,13 +72,13 @@ def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=Fal
     return u, s, vt
 
 
-def emu_power_iter(a, width, q, omega=None):
+def emu_power_iter(a, width, q, omega=None, qr=None):
     e = emu()
     a = np.asarray(a)
     suf = "f32" if a.dtype == np.float32 else "f64"
     m, n = a.shape
     rs, cs = a.strides[0] // a.itemsize, a.strides[1] // a.itemsize
-    o, keep = _opts(omega, n, width, a.dtype)
+    o, keep = _opts(omega, n, width, a.dtype, None, L.QR_HOUSEHOLDER if qr == "householder" else 0)
     qm = np.empty((m, width), dtype=a.dtype, order="F")
     i64 = C.c_int64
     rc = getattr(e, "corrla_emu_power_iter_" + suf)(C.c_void_p(a.ctypes.data), i64(m), i64(n), i64(rs), i64(cs),

@@ -261,3 +261,42 @@ def test_emu_blocked_cholesky_qr_for_wide_sketches(l):
     ex = np.linalg.svd(low, compute_uv=False)[:k]
     assert np.allclose(s.ravel(), ex, atol=1e-9 * ex[0])
     assert np.max(np.abs(u.T @ u - np.eye(k))) < 1e-10
+
+
+# ---- Householder TSQR thin-Q (CORRLA_QR_HOUSEHOLDER): same panel partition / pairwise tree / reverse application as
+# csrc/tsqr_kernels.hpp, run by the emulation backend through the real driver --------------------------------------
+@pytest.mark.parametrize("m,n,width", [(40, 12, 12), (700, 30, 17), (1301, 64, 40), (97, 48, 48), (5000, 20, 9)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_householder_tsqr_power_iter_spans_the_oracle_basis(m, n, width, dtype):
+    """panel counts 1, 2, odd (pass-through nodes), many; Q is orthonormal and spans the oracle's Householder Q."""
+    rng = np.random.default_rng(m + width)
+    a = rng.standard_normal((m, n)).astype(dtype)
+    om = rng.standard_normal((n, width)).astype(dtype)
+    q = emu_power_iter(a, width, 2, omega=om, qr="householder")
+    qo = orc.power_iter(a.astype(np.float64), om.astype(np.float64), 2)
+    tol = 5e-5 if dtype == np.float32 else 1e-10
+    assert np.max(np.abs(q.T.astype(np.float64) @ q - np.eye(width))) < tol
+    assert np.linalg.norm(q.astype(np.float64) @ (q.T.astype(np.float64) @ qo) - qo) < tol * 50
+
+
+def test_householder_tsqr_rsvd_matches_the_oracle_and_cholesky_path():
+    rng = np.random.default_rng(11)
+    a = (rng.standard_normal((900, 60)) * np.logspace(0, -6, 60)) @ rng.standard_normal((60, 60))
+    om = rng.standard_normal((60, 22))
+    uh, sh, vh = emu_rsvd(a, 12, 3, 10, omega=om, qr="householder")
+    uc, sc, vc = emu_rsvd(a, 12, 3, 10, omega=om)
+    uo, so, vo = orc.random_svd(a, 12, 3, 10, omega=om)
+    assert np.allclose(sh, so, rtol=1e-9) and np.allclose(sh, sc, rtol=1e-9)
+    assert abs(orc.relerr(a, uh, sh, vh) - orc.relerr(a, uo, so, vo)) < 1e-9
+    assert np.max(np.abs(uh.T @ uh - np.eye(12))) < 1e-12 and np.max(np.abs(vh @ vh.T - np.eye(12))) < 1e-12
+
+
+def test_householder_tsqr_is_orthonormal_for_rank_deficient_sketches():
+    """A Householder thin-Q is orthonormal whatever the rank (random_svd.rs:38,57): exact rank 3, sketch width 10."""
+    rng = np.random.default_rng(12)
+    a = rng.standard_normal((400, 3)) @ rng.standard_normal((3, 40))
+    q = emu_power_iter(a, 10, 1, omega=rng.standard_normal((40, 10)), qr="householder")
+    assert np.max(np.abs(q.T @ q - np.eye(10))) < 1e-12
+    u, s, vt = emu_rsvd(a, 6, 2, 4, omega=rng.standard_normal((40, 10)), qr="householder")
+    assert np.allclose(s[:3, 0], np.linalg.svd(a, compute_uv=False)[:3], rtol=1e-10) and np.all(s[3:, 0] < 1e-10 * s[0, 0])
+    assert np.max(np.abs(u.T @ u - np.eye(6))) < 1e-10

@@ -515,6 +515,66 @@ def test_drop_in_pydmdc_class(ctx):
     assert pred.shape[0] == 50 and np.max(np.abs(pred[:, 19] - snaps[:, 20])) < 5e-2
 
 
+# ---- Householder TSQR thin-Q (CORRLA_QR_HOUSEHOLDER, csrc/tsqr_kernels.hpp) --------------------------------------
+@pytest.mark.parametrize("name", ["tall64x48", "lowrank256x96", "gauss512x256", "fat48x64", "square40_lcap", "rankdef96x40", "known5x5_k5"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_householder_tsqr_rsvd_on_the_golden_fixtures(ctx, name, dtype):
+    from oracle import rsvd_oracle as orc
+    g = load_golden(name)
+    a, om = g["A"].astype(dtype), g["omega"].astype(dtype)
+    u, s, vt = ctx.rsvd(a, g["k"], g["q"], g["p"], omega=om, qr="householder")
+    uo, so, vo = orc.random_svd(g["A"], g["k"], g["q"], g["p"], omega=g["omega"])
+    tol = 1e-9 if dtype == np.float64 else 2e-4
+    assert np.max(np.abs(s.ravel() - so.ravel())) < tol * so[0, 0]
+    if dtype == np.float64 or name in ("tall64x48", "gauss512x256", "fat48x64"):   # f32: the well-posed sketches
+        assert abs(orc.relerr(a, u, s, vt) - orc.relerr(g["A"], uo, so, vo)) < (1e-9 if dtype == np.float64 else 1e-5)
+    k = g["k"]
+    otol = 1e-12 if dtype == np.float64 else 2e-5
+    assert np.max(np.abs(u.T.astype(np.float64) @ u - np.eye(k))) < otol
+    assert np.max(np.abs(vt.astype(np.float64) @ vt.T - np.eye(k))) < otol
+
+
+@pytest.mark.parametrize("m,n,width,dtype", [(5000, 300, 138, np.float32), (20000, 200, 97, np.float64), (277, 150, 138, np.float32),
+                                             (100000, 64, 32, np.float64), (1000, 40, 1, np.float32), (3001, 90, 33, np.float64)])
+def test_householder_tsqr_power_iter_q(ctx, m, n, width, dtype):
+    """Widest panels that fit in LDS (l = 138 f32 / 97 f64), a single leaf, odd panel counts, many panels: Q orthonormal
+    and spanning the oracle's Householder Q of the same sketch."""
+    from oracle import rsvd_oracle as orc
+    rng = np.random.default_rng(m + width)
+    a = rng.standard_normal((m, n)).astype(dtype)
+    om = rng.standard_normal((n, width)).astype(dtype)
+    q = ctx.power_iter(a, width, 1, omega=om, qr="householder")
+    qo = orc.power_iter(a.astype(np.float64), om.astype(np.float64), 1)
+    q64 = q.astype(np.float64)
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    assert np.max(np.abs(q64.T @ q64 - np.eye(width))) < tol
+    assert np.linalg.norm(q64 @ (q64.T @ qo) - qo) < tol * 100
+
+
+def test_householder_tsqr_rank_deficient_and_fallbacks(ctx, torch, monkeypatch):
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((3000, 4)) @ rng.standard_normal((4, 60))          # exact rank 4, sketch width 20
+    q = ctx.power_iter(a, 20, 1, omega=rng.standard_normal((60, 20)), qr="householder")
+    assert np.max(np.abs(q.T @ q - np.eye(20))) < 1e-12                        # orthonormal whatever the rank
+    u, s, vt = ctx.rsvd(a, 10, 2, 10, seed=1, qr="householder")
+    assert np.allclose(s[:4, 0], np.linalg.svd(a, compute_uv=False)[:4], rtol=1e-10) and np.all(s[4:, 0] < 1e-9 * s[0, 0])
+    assert np.max(np.abs(u.T @ u - np.eye(10))) < 1e-10 and np.max(np.abs(vt @ vt.T - np.eye(10))) < 1e-10
+    # a sketch wider than one LDS panel (l = 160 f64) takes the default path; CUDA tensors and the environment switch
+    b = rng.standard_normal((2000, 400))
+    u1, s1, vt1 = ctx.rsvd(b, 150, 1, 10, seed=2, qr="householder")
+    u0, s0, vt0 = ctx.rsvd(b, 150, 1, 10, seed=2)
+    assert np.array_equal(s0, s1)
+    bt = torch.as_tensor(b[:, :100].copy(), device="cuda")
+    ud, sd, vtd = ctx.rsvd(bt, 20, 2, 10, seed=4, qr="householder")
+    monkeypatch.setenv("CORRLA_QR", "householder")
+    ue, se, vte = ctx.rsvd(bt, 20, 2, 10, seed=4)
+    monkeypatch.delenv("CORRLA_QR")
+    uc, sc, vtc = ctx.rsvd(bt, 20, 2, 10, seed=4)
+    assert torch.equal(sd, se) and torch.allclose(sd, sc, rtol=1e-10) and not torch.equal(ud, uc)
+    with pytest.raises(ValueError):
+        ctx.rsvd(b, 10, 1, 5, qr="givens")
+
+
 # ---- SURVEY 8 f3: DMDc / POD with the n_x- and N-sized factors resident on the device ---------------------------
 def _lti_snapshots(n_x, n_t, k, n_u, seed):
     """x_{t+1} = A x_t + B u_t with rank-k dynamics inside an n_x-dimensional state (distinct stable eigenvalues)."""
