@@ -27,26 +27,34 @@ constexpr int kHhThreads = 512;  // 8 waves per panel
 constexpr int kHhWaves = kHhThreads / 64;
 constexpr int kHhMaxRowsPerLane = 5;  // ceil(2 * 138 / 64): panel rows a lane may own in one column
 
-template <int CTRL>
+template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float hh_dpp_f(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, true));
 }
-template <int CTRL>
+template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ double hh_dpp_f(double x) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-// sum over the 64 lanes, result in every lane (DPP inside the 16-lane rows, two cross-row exchanges)
+__device__ __forceinline__ float hh_readlane63(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ double hh_readlane63(double x) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+// sum over the 64 lanes, result in every lane: DPP inside the 16-lane rows, then the GFX9 row broadcasts (row 0 -> 1,
+// row 2 -> 3, then rows 0+1 -> 2, 3; masked-off rows receive 0 through bound_ctrl) leave the total in lane 63, which
+// is read back through a scalar register -- no LDS-crossbar exchange on the dependent chain
 template <class T>
 __device__ __forceinline__ T hh_wave_sum(T x) {
-  x += hh_dpp_f<0xB1>(x);   // quad_perm [1,0,3,2]
-  x += hh_dpp_f<0x4E>(x);   // quad_perm [2,3,0,1]
-  x += hh_dpp_f<0x141>(x);  // row_half_mirror
-  x += hh_dpp_f<0x140>(x);  // row_mirror
-  x += __shfl_xor(x, 16, 64);
-  x += __shfl_xor(x, 32, 64);
-  return x;
+  x += hh_dpp_f<0xB1>(x);        // quad_perm [1,0,3,2]
+  x += hh_dpp_f<0x4E>(x);        // quad_perm [2,3,0,1]
+  x += hh_dpp_f<0x141>(x);       // row_half_mirror
+  x += hh_dpp_f<0x140>(x);       // row_mirror: every lane holds the sum of its row
+  x += hh_dpp_f<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+  x += hh_dpp_f<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
+  return hh_readlane63(x);
 }
 
 __host__ __device__ inline int hh_pitch(int rows) { return (rows + 3) & ~3; }
