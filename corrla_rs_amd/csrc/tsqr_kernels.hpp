@@ -23,8 +23,9 @@
 namespace corrla {
 namespace k {
 
-constexpr int kHhThreads = 512;  // 8 waves per panel
+constexpr int kHhThreads = 1024;  // 16 waves per panel: four per SIMD hide the load -> reduce -> update chain of a column group
 constexpr int kHhWaves = kHhThreads / 64;
+constexpr int kHhGroup = 3;  // columns of one wave in flight together (138 columns = 16 waves x 3 groups of 3)
 constexpr int kHhMaxRowsPerLane = 5;  // ceil(2 * 138 / 64): panel rows a lane may own in one column
 
 template <int CTRL, int ROW_MASK = 0xf>
@@ -103,32 +104,33 @@ __device__ void hh_factor_panel(T* P, int RP, int rows, int l, T* tau_out) {
         tau_out[j] = tau;
       }
     }
-    // trailing update, four columns of this wave at a time: every LDS load is unconditional (clamped row / column
+    // trailing update, kHhGroup columns of this wave at a time: every LDS load is unconditional (clamped row / column
     // index; v is zero on the rows that do not exist) so that the twenty loads of a group are in flight together,
     // the four reductions overlap, and the update is made from registers
     int rr[kHhMaxRowsPerLane];
 #pragma unroll
     for (int i = 0; i < kHhMaxRowsPerLane; ++i) rr[i] = min(j + 1 + lane + 64 * i, rows - 1);
-    for (int c0 = j + 1 + 4 * wave; c0 < l; c0 += 4 * kHhWaves) {
-      T pv[4][kHhMaxRowsPerLane], pj[4], d[4];
+    // columns are dealt round-robin (column j + 1 + wave + 16 i), kHhGroup of a wave's columns at a time
+    for (int c0 = j + 1 + wave; c0 < l; c0 += kHhGroup * kHhWaves) {
+      T pv[kHhGroup][kHhMaxRowsPerLane], pj[kHhGroup], d[kHhGroup];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const T* cc = P + (size_t)min(c0 + u, l - 1) * RP;
+      for (int u = 0; u < kHhGroup; ++u) {
+        const T* cc = P + (size_t)min(c0 + u * kHhWaves, l - 1) * RP;
         pj[u] = cc[j];
 #pragma unroll
         for (int i = 0; i < kHhMaxRowsPerLane; ++i) pv[u][i] = cc[rr[i]];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kHhGroup; ++u) {
         d[u] = (T)0;
 #pragma unroll
         for (int i = 0; i < kHhMaxRowsPerLane; ++i) d[u] += xr[i] * pv[u][i];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) d[u] = hh_wave_sum(d[u]);
+      for (int u = 0; u < kHhGroup; ++u) d[u] = hh_wave_sum(d[u]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = c0 + u;
+      for (int u = 0; u < kHhGroup; ++u) {
+        const int c = c0 + u * kHhWaves;
         if (c < l) {
           T* cc = P + (size_t)c * RP;
           const T w = tau * (d[u] + pj[u]);
@@ -171,26 +173,26 @@ __device__ void hh_apply_panel(T* P, int RP, int rows, int l, const T* __restric
     int rr[kHhMaxRowsPerLane];
 #pragma unroll
     for (int i = 0; i < kHhMaxRowsPerLane; ++i) rr[i] = min(j + 1 + lane + 64 * i, rows - 1);
-    for (int c0 = 4 * wave; c0 < l; c0 += 4 * kHhWaves) {
-      T pv[4][kHhMaxRowsPerLane], pj[4], d[4];
+    for (int c0 = wave; c0 < l; c0 += kHhGroup * kHhWaves) {
+      T pv[kHhGroup][kHhMaxRowsPerLane], pj[kHhGroup], d[kHhGroup];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const T* cc = P + (size_t)min(c0 + u, l - 1) * RP;
+      for (int u = 0; u < kHhGroup; ++u) {
+        const T* cc = P + (size_t)min(c0 + u * kHhWaves, l - 1) * RP;
         pj[u] = cc[j];
 #pragma unroll
         for (int i = 0; i < kHhMaxRowsPerLane; ++i) pv[u][i] = cc[rr[i]];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kHhGroup; ++u) {
         d[u] = (T)0;
 #pragma unroll
         for (int i = 0; i < kHhMaxRowsPerLane; ++i) d[u] += v[i] * pv[u][i];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) d[u] = hh_wave_sum(d[u]);
+      for (int u = 0; u < kHhGroup; ++u) d[u] = hh_wave_sum(d[u]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = c0 + u;
+      for (int u = 0; u < kHhGroup; ++u) {
+        const int c = c0 + u * kHhWaves;
         if (c < l) {
           T* cc = P + (size_t)c * RP;
           const T w = tau * (d[u] + pj[u]);
