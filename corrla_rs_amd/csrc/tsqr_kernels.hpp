@@ -27,6 +27,7 @@ constexpr int kHhThreads = 1024;  // 16 waves per panel: four per SIMD hide the 
 constexpr int kHhWaves = kHhThreads / 64;
 constexpr int kHhGroup = 3;  // columns of one wave in flight together (138 columns = 16 waves x 3 groups of 3)
 constexpr int kHhMaxRowsPerLane = 5;  // ceil(2 * 138 / 64): panel rows a lane may own in one column
+constexpr int kHhTriSlices = 3;       // ceil(138 / 64): rows l .. l + j of a stacked-triangle panel
 
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float hh_dpp_f(float x) {
@@ -67,23 +68,26 @@ __host__ __device__ inline int64_t hh_leaf_row0(int64_t m, int nleaf, int i) { r
 
 // In-LDS Householder reduction of the rows x l panel P (column pitch RP).  On return the upper triangle holds R and
 // column j holds v_j below the diagonal (v_j(j) = 1 implied); tau[j] is written to global memory by wave 0.
-template <class T>
+// TRI: the panel is two stacked upper triangles [R_a; R_b] (rows = 2 l).  Reflector j then only involves row j and rows
+// l .. l + j (everything else of column j below the diagonal is, and stays, zero): NS = 3 row slices instead of 5.
+template <class T, int NS, bool TRI>
 __device__ void hh_factor_panel(T* P, int RP, int rows, int l, T* tau_out) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int j = 0; j < l; ++j) {
     T* cj = P + (size_t)j * RP;
+    const int lo = TRI ? l : j + 1, hi = TRI ? l + j + 1 : rows;  // rows [lo, hi) carry v below the diagonal
     // every wave forms the reflector redundantly (identical arithmetic -> identical values): no exchange needed
-    T xr[kHhMaxRowsPerLane];
+    T xr[NS];
     T part = (T)0;
 #pragma unroll
-    for (int i = 0; i < kHhMaxRowsPerLane; ++i) {
-      const int r = j + 1 + lane + 64 * i;
-      const T val = cj[min(r, rows - 1)];  // unconditional load (clamped), then select: the five loads overlap
-      xr[i] = r < rows ? val : (T)0;
+    for (int i = 0; i < NS; ++i) {
+      const int r = lo + lane + 64 * i;
+      const T val = cj[min(r, hi - 1)];  // unconditional load (clamped), then select: the five loads overlap
+      xr[i] = r < hi ? val : (T)0;
       part += xr[i] * xr[i];
     }
     const T sigma = hh_wave_sum(part);
-    const T alpha = j < rows ? cj[j] : (T)0;
+    const T alpha = cj[j];
     T tau = (T)0, beta = alpha, scale = (T)0;
     if (sigma > (T)0) {  // LAPACK xLARFG
       beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
@@ -91,40 +95,40 @@ __device__ void hh_factor_panel(T* P, int RP, int rows, int l, T* tau_out) {
       scale = (T)1 / (alpha - beta);
     }
 #pragma unroll
-    for (int i = 0; i < kHhMaxRowsPerLane; ++i) xr[i] *= scale;  // v below the diagonal
+    for (int i = 0; i < NS; ++i) xr[i] *= scale;  // v below the diagonal
     __syncthreads();  // everyone has read column j
     if (wave == 0) {
 #pragma unroll
-      for (int i = 0; i < kHhMaxRowsPerLane; ++i) {
-        const int r = j + 1 + lane + 64 * i;
-        if (r < rows) cj[r] = xr[i];
+      for (int i = 0; i < NS; ++i) {
+        const int r = lo + lane + 64 * i;
+        if (r < hi) cj[r] = xr[i];
       }
       if (lane == 0) {
-        if (j < rows) cj[j] = beta;
+        cj[j] = beta;
         tau_out[j] = tau;
       }
     }
     // trailing update, kHhGroup columns of this wave at a time: every LDS load is unconditional (clamped row / column
     // index; v is zero on the rows that do not exist) so that the twenty loads of a group are in flight together,
     // the four reductions overlap, and the update is made from registers
-    int rr[kHhMaxRowsPerLane];
+    int rr[NS];
 #pragma unroll
-    for (int i = 0; i < kHhMaxRowsPerLane; ++i) rr[i] = min(j + 1 + lane + 64 * i, rows - 1);
+    for (int i = 0; i < NS; ++i) rr[i] = min(lo + lane + 64 * i, hi - 1);
     // columns are dealt round-robin (column j + 1 + wave + 16 i), kHhGroup of a wave's columns at a time
     for (int c0 = j + 1 + wave; c0 < l; c0 += kHhGroup * kHhWaves) {
-      T pv[kHhGroup][kHhMaxRowsPerLane], pj[kHhGroup], d[kHhGroup];
+      T pv[kHhGroup][NS], pj[kHhGroup], d[kHhGroup];
 #pragma unroll
       for (int u = 0; u < kHhGroup; ++u) {
         const T* cc = P + (size_t)min(c0 + u * kHhWaves, l - 1) * RP;
         pj[u] = cc[j];
 #pragma unroll
-        for (int i = 0; i < kHhMaxRowsPerLane; ++i) pv[u][i] = cc[rr[i]];
+        for (int i = 0; i < NS; ++i) pv[u][i] = cc[rr[i]];
       }
 #pragma unroll
       for (int u = 0; u < kHhGroup; ++u) {
         d[u] = (T)0;
 #pragma unroll
-        for (int i = 0; i < kHhMaxRowsPerLane; ++i) d[u] += xr[i] * pv[u][i];
+        for (int i = 0; i < NS; ++i) d[u] += xr[i] * pv[u][i];
       }
 #pragma unroll
       for (int u = 0; u < kHhGroup; ++u) d[u] = hh_wave_sum(d[u]);
@@ -135,9 +139,9 @@ __device__ void hh_factor_panel(T* P, int RP, int rows, int l, T* tau_out) {
           T* cc = P + (size_t)c * RP;
           const T w = tau * (d[u] + pj[u]);
 #pragma unroll
-          for (int i = 0; i < kHhMaxRowsPerLane; ++i) {
-            const int r = j + 1 + lane + 64 * i;
-            if (r < rows) cc[r] = pv[u][i] - w * xr[i];
+          for (int i = 0; i < NS; ++i) {
+            const int r = lo + lane + 64 * i;
+            if (r < hi) cc[r] = pv[u][i] - w * xr[i];
           }
           if (lane == 0) cc[j] = pj[u] - w;
         }
@@ -149,44 +153,46 @@ __device__ void hh_factor_panel(T* P, int RP, int rows, int l, T* tau_out) {
 
 // P <- H_0 H_1 ... H_{l-1} P for the rows x l panel P in LDS; reflectors (V, leading dimension ldv) and tau in global
 // memory.  A wave owns its columns throughout: no barriers.
-template <class T>
+template <class T, int NS, bool TRI>
 __device__ void hh_apply_panel(T* P, int RP, int rows, int l, const T* __restrict__ V, int64_t ldv,
                                const T* __restrict__ tau_in) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  T vn[kHhMaxRowsPerLane];
+  T vn[NS];
   auto load_v = [&](int j) {
 #pragma unroll
-    for (int i = 0; i < kHhMaxRowsPerLane; ++i) {
-      const int r = j + 1 + lane + 64 * i;
-      const T val = V[(int64_t)max(j, 0) * ldv + min(r, rows - 1)];  // unconditional, clamped
-      vn[i] = (j >= 0 && r < rows) ? val : (T)0;
+    for (int i = 0; i < NS; ++i) {
+      const int lo_ = TRI ? l : j + 1, hi_ = TRI ? l + max(j, 0) + 1 : rows;
+      const int r = lo_ + lane + 64 * i;
+      const T val = V[(int64_t)max(j, 0) * ldv + min(r, hi_ - 1)];  // unconditional, clamped
+      vn[i] = (j >= 0 && r < hi_) ? val : (T)0;
     }
   };
   load_v(l - 1);
   for (int j = l - 1; j >= 0; --j) {
-    T v[kHhMaxRowsPerLane];
+    T v[NS];
 #pragma unroll
-    for (int i = 0; i < kHhMaxRowsPerLane; ++i) v[i] = vn[i];
+    for (int i = 0; i < NS; ++i) v[i] = vn[i];
     const T tau = tau_in[j];
     load_v(j - 1);  // the next reflector travels while this one is applied
     if (tau == (T)0) continue;
-    int rr[kHhMaxRowsPerLane];
+    const int lo = TRI ? l : j + 1, hi = TRI ? l + j + 1 : rows;
+    int rr[NS];
 #pragma unroll
-    for (int i = 0; i < kHhMaxRowsPerLane; ++i) rr[i] = min(j + 1 + lane + 64 * i, rows - 1);
+    for (int i = 0; i < NS; ++i) rr[i] = min(lo + lane + 64 * i, hi - 1);
     for (int c0 = wave; c0 < l; c0 += kHhGroup * kHhWaves) {
-      T pv[kHhGroup][kHhMaxRowsPerLane], pj[kHhGroup], d[kHhGroup];
+      T pv[kHhGroup][NS], pj[kHhGroup], d[kHhGroup];
 #pragma unroll
       for (int u = 0; u < kHhGroup; ++u) {
         const T* cc = P + (size_t)min(c0 + u * kHhWaves, l - 1) * RP;
         pj[u] = cc[j];
 #pragma unroll
-        for (int i = 0; i < kHhMaxRowsPerLane; ++i) pv[u][i] = cc[rr[i]];
+        for (int i = 0; i < NS; ++i) pv[u][i] = cc[rr[i]];
       }
 #pragma unroll
       for (int u = 0; u < kHhGroup; ++u) {
         d[u] = (T)0;
 #pragma unroll
-        for (int i = 0; i < kHhMaxRowsPerLane; ++i) d[u] += v[i] * pv[u][i];
+        for (int i = 0; i < NS; ++i) d[u] += v[i] * pv[u][i];
       }
 #pragma unroll
       for (int u = 0; u < kHhGroup; ++u) d[u] = hh_wave_sum(d[u]);
@@ -197,9 +203,9 @@ __device__ void hh_apply_panel(T* P, int RP, int rows, int l, const T* __restric
           T* cc = P + (size_t)c * RP;
           const T w = tau * (d[u] + pj[u]);
 #pragma unroll
-          for (int i = 0; i < kHhMaxRowsPerLane; ++i) {
-            const int r = j + 1 + lane + 64 * i;
-            if (r < rows) cc[r] = pv[u][i] - w * v[i];
+          for (int i = 0; i < NS; ++i) {
+            const int r = lo + lane + 64 * i;
+            if (r < hi) cc[r] = pv[u][i] - w * v[i];
           }
           if (lane == 0) cc[j] = pj[u] - w;
         }
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(kHhThreads) void hh_leaf_factor_kernel(const T* __r
     P[(size_t)c * RP + r] = y[(int64_t)c * ldy + r0 + r];
   }
   __syncthreads();
-  hh_factor_panel(P, RP, rows, l, tau + (size_t)node * l);
+  hh_factor_panel<T, kHhMaxRowsPerLane, false>(P, RP, rows, l, tau + (size_t)node * l);
   for (int idx = threadIdx.x; idx < rows * l; idx += kHhThreads) {
     const int c = idx / rows, r = idx - c * rows;
     v[(int64_t)c * ldv + r0 + r] = P[(size_t)c * RP + r];
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(kHhThreads) void hh_tree_factor_kernel(const T* __r
     P[(size_t)c * RP + l + r] = rin[(size_t)b * l * l + idx];
   }
   __syncthreads();
-  hh_factor_panel(P, RP, rows, l, tau + (size_t)node * l);
+  hh_factor_panel<T, kHhTriSlices, true>(P, RP, rows, l, tau + (size_t)node * l);
   T* vo = v + (size_t)node * rows * l;
   for (int idx = threadIdx.x; idx < rows * l; idx += kHhThreads) {
     const int c = idx / rows, r = idx - c * rows;
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(kHhThreads) void hh_tree_apply_kernel(const T* __re
     P[(size_t)c * RP + l + r] = (T)0;
   }
   __syncthreads();
-  hh_apply_panel(P, RP, rows, l, v + (size_t)node * rows * l, (int64_t)rows, tau + (size_t)node * l);
+  hh_apply_panel<T, kHhTriSlices, true>(P, RP, rows, l, v + (size_t)node * rows * l, (int64_t)rows, tau + (size_t)node * l);
   __syncthreads();
   for (int idx = threadIdx.x; idx < l * l; idx += kHhThreads) {
     const int c = idx / l, r = idx - c * l;
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(kHhThreads) void hh_leaf_apply_kernel(const T* __re
     P[(size_t)c * RP + r] = val;
   }
   __syncthreads();
-  hh_apply_panel(P, RP, rows, l, v + r0, ldv, tau + (size_t)node * l);
+  hh_apply_panel<T, kHhMaxRowsPerLane, false>(P, RP, rows, l, v + r0, ldv, tau + (size_t)node * l);
   __syncthreads();
   for (int idx = threadIdx.x; idx < rows * l; idx += kHhThreads) {
     const int c = idx / rows, r = idx - c * rows;
