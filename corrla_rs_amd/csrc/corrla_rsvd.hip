@@ -244,8 +244,12 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     static bool attrs = false;
     if (!attrs) {
       CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       CORRLA_HIP(hipFuncSetAttribute((const void*)k::grad_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attrs = true;
     }
@@ -267,12 +271,20 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
       const size_t lds_knn = k::knn_mfma_lds_bytes(kk, nn, waves);
       if (lds_knn > (size_t)160 * 1024) throw Error(ST_EINVAL, "problem does not fit in LDS");
       const int64_t knn_blocks = (n_q + 16 * waves - 1) / (16 * waves);
-      if (waves == 4)
-        hipLaunchKernelGGL(k::knn_mfma_kernel<4>, dim3((unsigned)knn_blocks), dim3(256), lds_knn, dev.stream, (const double*)xt, ldt,
-                           (const double*)pnorm, n_pts, kk, qd, n_q, nn, nbr);
-      else
-        hipLaunchKernelGGL(k::knn_mfma_kernel<2>, dim3((unsigned)knn_blocks), dim3(128), lds_knn, dev.stream, (const double*)xt, ldt,
-                           (const double*)pnorm, n_pts, kk, qd, n_q, nn, nbr);
+      const int nks = k::knn_mfma_slices(kk);
+#define CORRLA_KNN_LAUNCH(W_, S_)                                                                                              \
+  hipLaunchKernelGGL((k::knn_mfma_kernel<W_, S_>), dim3((unsigned)knn_blocks), dim3(64 * W_), lds_knn, dev.stream, (const double*)xt, \
+                     ldt, (const double*)pnorm, n_pts, kk, qd, n_q, nn, nbr)
+      if (waves == 4) {
+        if (nks == 4) CORRLA_KNN_LAUNCH(4, 4);
+        else if (nks == 8) CORRLA_KNN_LAUNCH(4, 8);
+        else CORRLA_KNN_LAUNCH(4, 16);
+      } else {
+        if (nks == 4) CORRLA_KNN_LAUNCH(2, 4);
+        else if (nks == 8) CORRLA_KNN_LAUNCH(2, 8);
+        else CORRLA_KNN_LAUNCH(2, 16);
+      }
+#undef CORRLA_KNN_LAUNCH
     }
     const int64_t ldgd = host_ptrs ? kf : ldg;
     hipLaunchKernelGGL(k::grad_fit_kernel, dim3((unsigned)n_q), dim3(64), lds_fit, dev.stream, xd, yd, kk, qd, n_q, (const int*)nbr,

@@ -170,18 +170,22 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
   x += __shfl_xor(x, 32, 64);
   return x;
 }
-template <int W>
+// NKS = number of 4-dimension MFMA slices compiled in (4, 8 or 16: k <= 16, 32, 64; unused slices multiply zeros).
+// A run-time slice count inside the unrolled loop made the compiler shuttle the sixteen accumulator registers between
+// AccVGPRs and VGPRs around every slice (~100 moves per slice, 6.7x the MFMA issue time of a chunk).
+template <int W, int NKS>
 __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restrict__ xt, int64_t ldt,
                                                           const double* __restrict__ pnorm, int64_t n_pts, int k,
                                                           const double* __restrict__ xq, int64_t n_q, int n_nbrs,
                                                           int* __restrict__ nbr) {
   constexpr int QT = 16 * W;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int k4 = (k + 3) & ~3, nks = k4 >> 2;
+  const int k4 = (k + 3) & ~3;
+  constexpr int KD = 4 * NKS;                       // staged dimensions (rows k .. KD - 1 are zero)
   double* qv = (double*)smem;                       // [QT][k4]
   double* qn = qv + (size_t)QT * k4;                // [QT]
-  double* pts = qn + QT;                            // [k4][kKnnPitch]
-  double* pn = pts + (size_t)k4 * kKnnPitch;        // [64]
+  double* pts = qn + QT;                            // [KD][kKnnPitch]
+  double* pn = pts + (size_t)KD * kKnnPitch;        // [64]
   double* ld = pn + 64;                             // [QT][n_nbrs]
   int* li = (int*)(ld + (size_t)QT * n_nbrs);       // [QT][n_nbrs]
   double* qmax = (double*)(li + (size_t)QT * n_nbrs + ((QT * n_nbrs) & 1));  // [QT] current n-th distance
@@ -208,9 +212,12 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
   }
   __syncthreads();
   // A fragments of this wave's 16 queries: lane (i = lane & 15, kk = lane >> 4) holds Q[i][4 ks + kk]
-  double afr[16];
+  double afr[NKS];
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) afr[ks] = ks < nks ? qv[(wave * 16 + (lane & 15)) * k4 + 4 * ks + (lane >> 4)] : 0.0;
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int d = 4 * ks + (lane >> 4);
+    afr[ks] = d < k4 ? qv[(wave * 16 + (lane & 15)) * k4 + d] : 0.0;
+  }
   // D layout: column (point) = lane & 15, row (query) = (lane >> 4) + 4 r
   double qn_r[4], tau_r[4];
 #pragma unroll
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
     for (int i = 0; i < PER; ++i) {
       const int idx = tid + i * 64 * W;
       const int d = idx >> 6, j = idx & 63;
-      if (d < k4) pts[d * kKnnPitch + j] = pre[i];
+      if (d < KD) pts[d * kKnnPitch + j] = pre[i];
     }
     if (tid < 64) pn[tid] = pre_n;
   };
@@ -254,12 +261,10 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
     for (int t = 0; t < 4; ++t) acc[t] = (knn_f64x4){0, 0, 0, 0};
     const double* bp = pts + (lane >> 4) * kKnnPitch + (lane & 15);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      if (ks < nks) {
+    for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], bp[(4 * ks) * kKnnPitch + 16 * t], acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < 4; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], bp[(4 * ks) * kKnnPitch + 16 * t], acc[t], 0, 0, 0);
     }
     unsigned hits = 0;
 #pragma unroll
@@ -350,9 +355,10 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
     nbr[(q0 + qq) * n_nbrs + rank] = ix;
   }
 }
+inline int knn_mfma_slices(int k) { return k <= 16 ? 4 : (k <= 32 ? 8 : 16); }
 inline size_t knn_mfma_lds_bytes(int k, int n_nbrs, int waves) {
-  const int k4 = (k + 3) & ~3, qt = 16 * waves;
-  return ((size_t)qt * k4 + qt + (size_t)k4 * kKnnPitch + 64 + (size_t)qt * n_nbrs + qt) * 8 + ((size_t)qt * n_nbrs + 1 + qt) * 4 + 64;
+  const int k4 = (k + 3) & ~3, qt = 16 * waves, kd = 4 * knn_mfma_slices(k);
+  return ((size_t)qt * k4 + qt + (size_t)kd * kKnnPitch + 64 + (size_t)qt * n_nbrs + qt) * 8 + ((size_t)qt * n_nbrs + 1 + qt) * 4 + 64;
 }
 // |p|^2 of every support point (from the dimension-major copy)
 __global__ void point_norms_kernel(const double* __restrict__ xt, int64_t ldt, int64_t n, int k, double* pn) {
