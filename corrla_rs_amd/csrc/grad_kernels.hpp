@@ -132,12 +132,13 @@ inline size_t knn_lds_bytes(int k, int n_nbrs) {
 
 // ---- k-NN with the distance tile on the f64 MFMA ---------------------------------------------------------
 // d^2(q, p) = |q|^2 + |p|^2 - 2 q.p: each wave owns 16 queries whose MFMA A-fragments (16 x 4 slices of the query
-// block) stay in registers for the whole scan; per chunk of 64 points it issues 4 x k/4 v_mfma_f64_16x16x4_f64 against
-// the LDS-staged points (row pitch 80 doubles: the two dimension rows of a 32-lane ds_read_b64 pass fall in different
-// bank halves).  The MFMA value is only a FILTER (margin 1e-12 (|q|^2 + |p|^2)); a candidate that passes gets its exact
+// block, f32) stay in registers for the whole scan; per chunk of 64 points it issues 4 x k/4 v_mfma_f32_16x16x4_f32
+// against an f32 copy of the LDS-staged points (row pitch 80: the four dimension rows of a fragment read fall in
+// disjoint banks); the norms are f64.  The f32 matrix unit runs at twice the f64 rate on MI355X and the MFMA value is
+// only a FILTER (margin 1e-5 (|q|^2 + |p|^2) covers the f32 rounding); a candidate that passes gets its exact
 // distance sum_d (p_d - q_d)^2 recomputed across the lanes before it may enter the sorted list, so the neighbour sets
 // and their order are those of the exact search.
-typedef double knn_f64x4 __attribute__((ext_vector_type(4)));
+typedef float knn_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kKnnPitch = 80;
 __device__ __forceinline__ double wave_max_f64(double x) {
   auto dpp = [](double v, auto ctrl) {
@@ -184,8 +185,9 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
   constexpr int KD = 4 * NKS;                       // staged dimensions (rows k .. KD - 1 are zero)
   double* qv = (double*)smem;                       // [QT][k4]
   double* qn = qv + (size_t)QT * k4;                // [QT]
-  double* pts = qn + QT;                            // [KD][kKnnPitch]
-  double* pn = pts + (size_t)KD * kKnnPitch;        // [64]
+  double* pts = qn + QT;                            // [KD][kKnnPitch]  (exact re-check)
+  float* ptsf = (float*)(pts + (size_t)KD * kKnnPitch);   // [KD][kKnnPitch]  f32 copy: the MFMA filter's B operand
+  double* pn = (double*)(ptsf + (size_t)KD * kKnnPitch);  // [64]
   double* ld = pn + 64;                             // [QT][n_nbrs]
   int* li = (int*)(ld + (size_t)QT * n_nbrs);       // [QT][n_nbrs]
   double* qmax = (double*)(li + (size_t)QT * n_nbrs + ((QT * n_nbrs) & 1));  // [QT] current n-th distance
@@ -211,18 +213,18 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
     qn[tid] = s;
   }
   __syncthreads();
-  // A fragments of this wave's 16 queries: lane (i = lane & 15, kk = lane >> 4) holds Q[i][4 ks + kk]
-  double afr[NKS];
+  // A fragments of this wave's 16 queries: lane (i = lane & 15, kk = lane >> 4) holds Q[i][4 ks + kk], in f32
+  float afr[NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     const int d = 4 * ks + (lane >> 4);
-    afr[ks] = d < k4 ? qv[(wave * 16 + (lane & 15)) * k4 + d] : 0.0;
+    afr[ks] = d < k4 ? (float)qv[(wave * 16 + (lane & 15)) * k4 + d] : 0.0f;
   }
-  // D layout: column (point) = lane & 15, row (query) = (lane >> 4) + 4 r
+  // D layout of v_mfma_f32_16x16x4_f32: column (point) = lane & 15, row (query) = 4 (lane >> 4) + r
   double qn_r[4], tau_r[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    qn_r[r] = qn[wave * 16 + (lane >> 4) + 4 * r];
+    qn_r[r] = qn[wave * 16 + 4 * (lane >> 4) + r];
     tau_r[r] = __builtin_huge_val();
   }
   const int64_t nchunks = (n_pts + 63) / 64;
@@ -245,7 +247,10 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
     for (int i = 0; i < PER; ++i) {
       const int idx = tid + i * 64 * W;
       const int d = idx >> 6, j = idx & 63;
-      if (d < KD) pts[d * kKnnPitch + j] = pre[i];
+      if (d < KD) {
+        pts[d * kKnnPitch + j] = pre[i];
+        ptsf[d * kKnnPitch + j] = (float)pre[i];
+      }
     }
     if (tid < 64) pn[tid] = pre_n;
   };
@@ -256,15 +261,15 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
     stash();
     __syncthreads();
     if (c + 1 < nchunks) fetch(c + 1);
-    knn_f64x4 acc[4];
+    knn_f32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (knn_f64x4){0, 0, 0, 0};
-    const double* bp = pts + (lane >> 4) * kKnnPitch + (lane & 15);
+    for (int t = 0; t < 4; ++t) acc[t] = (knn_f32x4){0, 0, 0, 0};
+    const float* bp = ptsf + (lane >> 4) * kKnnPitch + (lane & 15);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], bp[(4 * ks) * kKnnPitch + 16 * t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks], bp[(4 * ks) * kKnnPitch + 16 * t], acc[t], 0, 0, 0);
     }
     unsigned hits = 0;
 #pragma unroll
@@ -275,8 +280,10 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const double nsum = qn_r[r] + pnv;
-        const double dm = nsum - 2.0 * acc[t][r];
-        if (pvalid && dm - 1e-12 * nsum < tau_r[r]) hits |= 1u << (4 * t + r);
+        const double dm = nsum - 2.0 * (double)acc[t][r];
+        // f32 products and sums over <= 64 dimensions: |error of 2 q.p| < 4e-6 (|q|^2 + |p|^2); the negated comparison
+        // lets a non-finite value (f32 overflow) through to the exact re-check as well
+        if (pvalid && !(dm - 1e-5 * nsum >= tau_r[r])) hits |= 1u << (4 * t + r);
       }
     }
     if (__any(hits != 0)) {
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
           while (rb) {
             const int r = __ffs((int)rb) - 1;
             rb &= rb - 1;
-            const int qq = wave * 16 + (b >> 4) + 4 * r;
+            const int qq = wave * 16 + 4 * (b >> 4) + r;
             if (q0 + qq >= n_q) continue;  // padding query rows
             double df = 0.0;
             if (lane < k) df = pts[lane * kKnnPitch + pl] - qv[qq * k4 + lane];
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
         }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tau_r[r] = qmax[wave * 16 + (lane >> 4) + 4 * r];
+      for (int r = 0; r < 4; ++r) tau_r[r] = qmax[wave * 16 + 4 * (lane >> 4) + r];
     }
   }
   __syncthreads();
@@ -358,7 +365,8 @@ __global__ __launch_bounds__(64 * W) void knn_mfma_kernel(const double* __restri
 inline int knn_mfma_slices(int k) { return k <= 16 ? 4 : (k <= 32 ? 8 : 16); }
 inline size_t knn_mfma_lds_bytes(int k, int n_nbrs, int waves) {
   const int k4 = (k + 3) & ~3, qt = 16 * waves, kd = 4 * knn_mfma_slices(k);
-  return ((size_t)qt * k4 + qt + (size_t)kd * kKnnPitch + 64 + (size_t)qt * n_nbrs + qt) * 8 + ((size_t)qt * n_nbrs + 1 + qt) * 4 + 64;
+  return ((size_t)qt * k4 + qt + (size_t)kd * kKnnPitch + 64 + (size_t)qt * n_nbrs + qt) * 8 +
+         ((size_t)kd * kKnnPitch + (size_t)qt * n_nbrs + 1 + qt) * 4 + 64;
 }
 // |p|^2 of every support point (from the dimension-major copy)
 __global__ void point_norms_kernel(const double* __restrict__ xt, int64_t ldt, int64_t n, int k, double* pn) {
