@@ -506,7 +506,18 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
       __syncthreads();
       for (int c = j + 1 + lane; c < P; c += 64) {
         const double lcj = M[c * LM + j];
-        for (int i = c; i < P; ++i) M[i * LM + c] -= M[i * LM + j] * lcj;
+        int i = c;
+        // four rows at a time with all eight loads issued first: written as a plain read-modify-write loop the compiler
+        // must assume the store to M(i, c) aliases the next load and waits out one LDS round trip per row
+        for (; i + 3 < P; i += 4) {
+          const double a0 = M[i * LM + j], a1 = M[(i + 1) * LM + j], a2 = M[(i + 2) * LM + j], a3 = M[(i + 3) * LM + j];
+          const double m0 = M[i * LM + c], m1 = M[(i + 1) * LM + c], m2 = M[(i + 2) * LM + c], m3 = M[(i + 3) * LM + c];
+          M[i * LM + c] = m0 - a0 * lcj;
+          M[(i + 1) * LM + c] = m1 - a1 * lcj;
+          M[(i + 2) * LM + c] = m2 - a2 * lcj;
+          M[(i + 3) * LM + c] = m3 - a3 * lcj;
+        }
+        for (; i < P; ++i) M[i * LM + c] -= M[i * LM + j] * lcj;
       }
       __syncthreads();
     }
