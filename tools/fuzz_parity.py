@@ -50,7 +50,8 @@ def run(n_cases=200, seed=0, ctx=None, verbose=True):
       elif (sv[l - 1] / sv[0]) ** (2 * min(q, 3) + 1) < 1e4 * eps:
           continue
       try:
-          u, s, vt = ctx.rsvd(a, k, q, p, omega=om)
+          # a third of the cases through the Householder TSQR thin-Q (wider sketches fall back to the default inside)
+          u, s, vt = ctx.rsvd(a, k, q, p, omega=om, qr="householder" if rng.random() < 0.33 else None)
       except Exception as e:  # noqa: BLE001
           if verbose: print("EXCEPTION", case, (m, n), dtype.__name__, kind, k, q, p, repr(e)[:200])
           bad += 1
