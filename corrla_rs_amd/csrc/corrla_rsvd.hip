@@ -256,9 +256,9 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     if (lds_fit > (size_t)160 * 1024) throw Error(ST_EINVAL, "problem does not fit in LDS");
     if (n_q > 0x7fffffff) throw Error(ST_EINVAL, "too many query points for one launch");
     // Both kernels spend ~n_nbrs ln(n_pts / n_nbrs) list insertions per query; the MFMA distance tile only pays off
-    // once the scan itself dominates (measured cross-over between 1e5 and 1e6 support points)
+    // once the scan itself dominates (measured: 5e4 points 0.10 s VALU / 0.14 s MFMA, 1e5 0.28 / 0.30, 2e5 0.93 / 0.45)
     const int knn_mode = env_int("CORRLA_KNN", 0);  // 1: VALU kernel, 2: MFMA kernel, 0: by size
-    if (knn_mode == 1 || (knn_mode == 0 && n_pts < 262144)) {
+    if (knn_mode == 1 || (knn_mode == 0 && n_pts < 131072)) {
       const size_t lds_knn = k::knn_lds_bytes(kk, nn);
       const int64_t knn_blocks = (n_q + k::kKnnQueries - 1) / k::kKnnQueries;
       hipLaunchKernelGGL(k::knn_kernel, dim3((unsigned)knn_blocks), dim3(64 * k::kKnnWaves), lds_knn, dev.stream, (const double*)xt,
