@@ -18,6 +18,9 @@ CONFIGS = {
     "C4shard": (1_250_000, 512, torch.float32, 64, 2, 10),
     "C4full": (10_000_000, 512, torch.float32, 64, 2, 10),     # the whole 10^7 x 512 matrix (20.5 GB) on ONE GPU
     "C5": (1_000_000, 64, torch.float64, 32, 8, 10),
+    "C2x4": (32768, 32768, torch.float32, 128, 2, 10),          # 4.3 GB
+    "C2x16": (65536, 65536, torch.float32, 128, 2, 10),         # 17 GB, 2^32 elements: 64-bit indexing everywhere
+    "C2x16tall": (1_048_576, 4096, torch.float32, 128, 2, 10),  # same size, tall
     "C2col": (16384, 16384, torch.float32, 128, 2, 10),
 }
 names = sys.argv[1:] or ["C1", "C3q2", "C4shard", "C5", "C2col"]
