@@ -300,3 +300,13 @@ def test_householder_tsqr_is_orthonormal_for_rank_deficient_sketches():
     u, s, vt = emu_rsvd(a, 6, 2, 4, omega=rng.standard_normal((40, 10)), qr="householder")
     assert np.allclose(s[:3, 0], np.linalg.svd(a, compute_uv=False)[:3], rtol=1e-10) and np.all(s[3:, 0] < 1e-10 * s[0, 0])
     assert np.max(np.abs(u.T @ u - np.eye(6))) < 1e-10
+
+
+def test_householder_flag_on_the_sharded_entry_point_takes_the_default_path():
+    """Row-sharded calls have no cross-rank TSQR: the flag is accepted and the CholeskyQR2 path runs (same numbers)."""
+    rng = np.random.default_rng(14)
+    a = rng.standard_normal((300, 40))
+    om = rng.standard_normal((40, 14))
+    u1, s1, vt1 = emu_rsvd(a, 8, 2, 6, omega=om, sharded=True, qr="householder")
+    u0, s0, vt0 = emu_rsvd(a, 8, 2, 6, omega=om, sharded=True)
+    assert np.array_equal(s0, s1) and np.array_equal(u0, u1) and np.array_equal(vt0, vt1)
