@@ -434,7 +434,7 @@ struct RsvdDriver {
   // ---- power_iter, random_svd.rs:15-59 -------------------------------------------------
   // Leaves the orthonormal basis in `y` (mt x l) and returns its numerical rank.
   int64_t power_iter(const TallA<T>& a, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& y, Skinny<T>& y2) {
-    qr_householder = o.qr_householder;
+    qr_householder = o.qr_householder && !o.sharded;  // no cross-rank TSQR: sharded calls keep the default path
     PhaseTimer pt;
     Skinny<T> om = dev.template alloc_skinny<T>(a.nt, l);
     if (o.omega) {
@@ -481,7 +481,7 @@ struct RsvdDriver {
   // it runs again and overwrites them.
   void random_svd_tall(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
                        T* s_dev, Skinny<T>& v_tall, const std::function<void()>& emit = {}) {
-    qr_householder = o.qr_householder;
+    qr_householder = o.qr_householder && !o.sharded;  // no cross-rank TSQR: sharded calls keep the default path
     // Householder mode has no status records to defer: the body runs with the host in the loop, which also lets it
     // complete the null vectors of an exactly singular core (see random_svd_tall_body)
     const bool hh = qr_householder && !o.sharded && dev.template householder_fits<T>(l);
