@@ -14,6 +14,7 @@ OMEGA_ON_DEVICE = 0x1
 PCA_CENTER_FUSED = 0x2
 PCA_CENTER_COPY = 0x4
 QR_HOUSEHOLDER = 0x8
+SEED_EXPLICIT = 0x10
 UNIQUE_ID_BYTES = 128
 
 

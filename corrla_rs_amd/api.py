@@ -103,7 +103,7 @@ class Context:
         o = L.Opts()
         o.struct_size = C.sizeof(L.Opts)
         o.seed = int(seed) if seed is not None else 0
-        o.flags = int(extra_flags)
+        o.flags = int(extra_flags) | (L.SEED_EXPLICIT if seed is not None else 0)   # seed=0 is a real seed
         keep = None
         if omega is not None:
             if on_device:

@@ -12,6 +12,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcorrla_rsvd.so")
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_PATH = os.path.join(EMU_DIR, "libcorrla_emu.so")
+EMU_ASAN_PATH = os.path.join(EMU_DIR, "libcorrla_emu_asan.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 
@@ -51,18 +52,25 @@ def build_product(force=False, verbose=False):
     return LIB_PATH
 
 
-def build_emu(force=False, verbose=False):
-    """g++ -> tests/emu/libcorrla_emu.so (test infrastructure: host emulation of the device backend)"""
+def build_emu(force=False, verbose=False, asan=False):
+    """g++ -> tests/emu/libcorrla_emu.so (test infrastructure: host emulation of the device backend).
+    asan=True builds tests/emu/libcorrla_emu_asan.so with -fsanitize=address,undefined: the host-side driver and C-ABI
+    glue (driver.hpp, capi_impl.hpp, small_linalg.hpp) under the sanitizers -- CPU only, never on the GPU box.  Run the
+    CPU suite against it with
+        CORRLA_EMU_ASAN=1 LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 \
+            python -m pytest tests -m "not gpu" """
     srcs = _sources(CSRC, (".hpp", ".h")) + [os.path.join(EMU_DIR, "emu_backend.cpp"),
                                              os.path.join(ROOT, "include", "corrla_rsvd.h")]
-    if not force and _newer(EMU_PATH, srcs):
-        return EMU_PATH
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(EMU_DIR, "emu_backend.cpp"), "-o", EMU_PATH]
+    out = EMU_ASAN_PATH if asan else EMU_PATH
+    if not force and _newer(out, srcs):
+        return out
+    opt = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if asan else ["-O2"]
+    cmd = ["g++", *opt, "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(EMU_DIR, "emu_backend.cpp"), "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return EMU_PATH
+    return out
 
 
 if __name__ == "__main__":
@@ -70,3 +78,5 @@ if __name__ == "__main__":
     print(build_product(force=force, verbose=True))
     if "--emu" in sys.argv:
         print(build_emu(force=force, verbose=True))
+    if "--emu-asan" in sys.argv:
+        print(build_emu(force=force, verbose=True, asan=True))

@@ -40,7 +40,10 @@ inline RunOpts parse_opts(const corrla_opts* o, bool dev_ptrs) {
   r.qr_householder = qr_env && std::strcmp(qr_env, "householder") == 0;
   if (!o) return r;
   if (o->struct_size != sizeof(corrla_opts)) throw Error(ST_EINVAL, "corrla_opts.struct_size mismatch");
-  r.seed = o->seed ? o->seed : r.seed;
+  // seed: used as given when it is non-zero or CORRLA_SEED_EXPLICIT is set (so 0 is a usable seed); otherwise every
+  // call draws a fresh sketch like the reference's unseeded thread_rng (mat_utils.rs:161-175) -- see fresh_seed()
+  r.seed_explicit = o->seed != 0 || (o->flags & CORRLA_SEED_EXPLICIT) != 0;
+  if (r.seed_explicit) r.seed = o->seed;
   r.omega = o->omega;
   r.omega_ld = o->omega_ld;
   r.omega_on_device = (o->flags & CORRLA_OMEGA_ON_DEVICE) != 0;
@@ -143,6 +146,7 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
   if (ldvt < rank) throw Error(ST_EINVAL, "ldvt < rank");
   RunOpts ro = parse_opts(opts, !host_ptrs);
   ro.sharded = sharded;
+  if (!ro.seed_explicit && !ro.omega) ro.seed = dev.fresh_seed(/*rank_invariant=*/sharded);
   dev.begin_call();
   TallA<T> ta = stage_input<Dev, T>(dev, host_ptrs, a, m, n, rs, cs, sharded);
   const bool fat = !sharded && m < n;
@@ -181,6 +185,7 @@ inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n
   if (m < 2) throw Error(ST_EINVAL, "PCA needs at least two samples");
   if (ldc < rank) throw Error(ST_EINVAL, "ldc < rank");
   RunOpts ro = parse_opts(opts, !host_ptrs);
+  if (!ro.seed_explicit && !ro.omega) ro.seed = dev.fresh_seed(false);
   dev.begin_call();
   TallA<T> ta = stage_input<Dev, T>(dev, host_ptrs, x, m, n, rs, cs, false);
   const bool fat = m < n;  // the tall view is x^T: its ROWS are the data columns
@@ -249,6 +254,7 @@ inline void power_iter_entry(Dev& dev, bool host_ptrs, const T* a, int64_t m, in
   if (ldq < m) throw Error(ST_EINVAL, "ldq < m");
   RunOpts ro = parse_opts(opts, !host_ptrs);
   if (ro.omega && ro.omega_ld < n) throw Error(ST_EINVAL, "omega_ld < n");
+  if (!ro.seed_explicit && !ro.omega) ro.seed = dev.fresh_seed(false);
   dev.begin_call();
   TallA<T> ta = stage_input<Dev, T>(dev, host_ptrs, a, m, n, rs, cs, /*force_tall=*/true);
   RsvdDriver<Dev, T> drv(dev, false);

@@ -15,13 +15,40 @@ struct corrla_ctx {
   Timings last;
   std::mutex mu;
   bool profile;
-  explicit corrla_ctx(int ordinal) : dev(ordinal), profile(env_int("CORRLA_PROFILE_PHASES", 0) != 0) {}
+  explicit corrla_ctx(int ordinal) : dev(ordinal), profile(env_int("CORRLA_PROFILE_PHASES", 0) != 0) {
+    // function attributes apply to the device that is current when they are set: once per context (HipDev's
+    // constructor has made `ordinal` current), like every other kernel's
+    const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_kernel, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4, 4>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4, 8>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2, 4>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2, 8>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::grad_fit_kernel, attr, 160 * 1024));
+  }
 };
 
 namespace {
 inline corrla_ctx* need(corrla_ctx* c) {
   if (!c) throw Error(ST_EINVAL, "ctx is NULL");
   return c;
+}
+// Runs one entry point under the context lock.  On the exception path the stream is drained before the status is
+// returned: kernels that write the caller's outputs, or still read the caller's Omega, may be queued, and the
+// caller is free to release those buffers as soon as the call has failed.
+template <class F>
+inline void locked_call(corrla_ctx* c, F&& f) {
+  std::lock_guard<std::mutex> lk(c->mu);
+  try {
+    f();
+  } catch (...) {
+    (void)hipSetDevice(c->dev.device);
+    if (c->dev.stream) (void)hipStreamSynchronize(c->dev.stream);
+    (void)hipGetLastError();
+    throw;
+  }
 }
 
 template <class T>
@@ -30,9 +57,10 @@ corrla_status rsvd_c(corrla_ctx* ctx, bool host, bool sharded, const T* a, int64
                      int64_t ldvt) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);
-    std::lock_guard<std::mutex> lk(c->mu);
-    rsvd_entry<HipDev, T>(c->dev, host, sharded, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt, &c->last,
-                          c->profile);
+    locked_call(c, [&] {
+      rsvd_entry<HipDev, T>(c->dev, host, sharded, a, m, n, rs, cs, rank, n_iter, p, o, u, ldu, s, vt, ldvt, &c->last,
+                            c->profile);
+    });
     if (c->profile && env_int("CORRLA_DEBUG", 0))
       std::fprintf(stderr, "[corrla] qr breakdown (ms): gram %.3f  download+check %.3f  host chol/inv %.3f  upload+apply %.3f  (%d passes)\n",
                    c->last.qr_gram_ms, c->last.qr_down_ms, c->last.qr_host_ms, c->last.qr_apply_ms, c->last.qr_passes);
@@ -43,8 +71,9 @@ corrla_status pca_c(corrla_ctx* ctx, bool host, const T* x, int64_t m, int64_t n
                     int64_t n_iter, int64_t p, const corrla_opts* o, T* means, T* s, T* comps, int64_t ldc) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);
-    std::lock_guard<std::mutex> lk(c->mu);
-    pca_entry<HipDev, T>(c->dev, host, x, m, n, rs, cs, rank, n_iter, p, o, means, s, comps, ldc, &c->last, c->profile);
+    locked_call(c, [&] {
+      pca_entry<HipDev, T>(c->dev, host, x, m, n, rs, cs, rank, n_iter, p, o, means, s, comps, ldc, &c->last, c->profile);
+    });
   });
 }
 template <class T>
@@ -52,8 +81,7 @@ corrla_status power_c(corrla_ctx* ctx, bool host, const T* a, int64_t m, int64_t
                       int64_t n_iter, const corrla_opts* o, T* q, int64_t ldq) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);
-    std::lock_guard<std::mutex> lk(c->mu);
-    power_iter_entry<HipDev, T>(c->dev, host, a, m, n, rs, cs, width, n_iter, o, q, ldq);
+    locked_call(c, [&] { power_iter_entry<HipDev, T>(c->dev, host, a, m, n, rs, cs, width, n_iter, o, q, ldq); });
   });
 }
 template <class T>
@@ -61,8 +89,7 @@ corrla_status matmul_c(corrla_ctx* ctx, int trans, const T* a, int64_t m, int64_
                        int64_t ldx, int64_t l, T beta, T* res, int64_t ldres) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);
-    std::lock_guard<std::mutex> lk(c->mu);
-    matmul_entry<HipDev, T>(c->dev, trans, a, m, n, rs, cs, x, ldx, l, beta, res, ldres);
+    locked_call(c, [&] { matmul_entry<HipDev, T>(c->dev, trans, a, m, n, rs, cs, x, ldx, l, beta, res, ldres); });
   });
 }
 template <class T>
@@ -214,7 +241,7 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     if (P > k::kGradMaxCols) throw Error(ST_EINVAL, "the design matrix would have more than 66 columns (order 2 needs k <= 10)");
     if (ldg < kf) throw Error(ST_EINVAL, "ldg < k");
     if (n_pts > 0x7fffffff || n_q * n_nbrs > ((int64_t)1 << 40)) throw Error(ST_EINVAL, "point set too large");
-    std::lock_guard<std::mutex> lk(c->mu);
+    locked_call(c, [&] {
     HipDev& dev = c->dev;
     dev.begin_call();
     const int kk = (int)kf, nn = (int)n_nbrs;
@@ -241,18 +268,6 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     hipLaunchKernelGGL(k::grad_transpose_kernel, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, dev.stream, xd, n_pts, kk, xt,
                        ldt);
     const size_t lds_fit = k::grad_fit_lds_bytes(kk, nn, est_order);
-    static bool attrs = false;
-    if (!attrs) {
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::knn_mfma_kernel<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::grad_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attrs = true;
-    }
     if (lds_fit > (size_t)160 * 1024) throw Error(ST_EINVAL, "problem does not fit in LDS");
     if (n_q > 0x7fffffff) throw Error(ST_EINVAL, "too many query points for one launch");
     // Both kernels spend ~n_nbrs ln(n_pts / n_nbrs) list insertions per query; the MFMA distance tile only pays off
@@ -300,6 +315,7 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     int bad = 0;
     for (int v : hs) bad += v != 0;
     if (n_regularised) *n_regularised = bad;
+    });
   });
 }
 CORRLA_API corrla_status corrla_grad_mat_f64(corrla_ctx* ctx, const double* x, int64_t n_pts, int64_t k, const double* y,

@@ -92,6 +92,7 @@ struct TallA {
 
 struct RunOpts {
   uint64_t seed = 0x5eedull;
+  bool seed_explicit = false;   // false: the entry point draws a fresh per-call seed (Dev::fresh_seed)
   const void* omega = nullptr;  // column-major nt x l, dtype T
   int64_t omega_ld = 0;
   bool omega_on_device = false;
@@ -174,17 +175,26 @@ struct RsvdDriver {
   // Returns the number of orthonormal columns (l unless the matrix has fewer rows than columns).
   // `rough`: stop after the first clean Cholesky pass -- enough for the in-loop re-orthonormalisations
   // (random_svd.rs:37-39), whose only role is to keep the sketch well conditioned; the span is unchanged.
-  static constexpr int kStatusSlots = 64;
   static constexpr size_t kStatusBytes = 32;  // one device status record (CholStatus)
+  int st_slots_ = 0;                          // records in the pool of the optimistic run (sized from n_iter)
   struct Pending {
     int slot, npass;
     bool rough;
     int per_pass;  // status records per pass: 1 (single factorisation) or 2 (2 x 2 blocked)
   };
   bool defer_status_ = false;
+  bool optimistic_dirty_ = false;  // a pass of the optimistic run took the host-controlled loop: repeat the call
   void* st_pool_ = nullptr;
   int st_used_ = 0;
   std::vector<Pending> pending_;
+  // rows of the WHOLE tall matrix (all ranks), fetched lazily by one scalar all-reduce the first time a rank-invariant
+  // decision needs it; -1 = unknown.  Unsharded calls use the local row count.
+  int64_t m_local_ = 0, m_global_ = -1;
+  int64_t global_rows(bool sharded) {
+    if (!sharded) return m_local_;
+    if (m_global_ < 0) m_global_ = dev.allreduce_sum_host(m_local_);
+    return m_global_;
+  }
 
   int64_t orthonormalize(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough = false) {
     const int64_t l = y.cols;
@@ -200,7 +210,9 @@ struct RsvdDriver {
     // A Householder thin-Q (random_svd.rs:38,57) is orthonormal whatever the rank of its input: the directions a
     // rank-deficient sketch does not determine are an arbitrary orthonormal completion.  Reproduce that instead of
     // leaving zero columns (in-loop, the completion re-seeds directions the next product with A can pick up again).
-    if (r < l && !defer_status_ && y.rows >= l) r = complete_basis(y, r, sharded);
+    // Sharded: every rank must take the same branch (complete_basis issues all-reduces), so the test uses the GLOBAL
+    // row count -- the local one differs between uneven shards -- and r itself derives from all-reduced Gram matrices.
+    if (r < l && !defer_status_ && (sharded ? global_rows(true) : y.rows) >= l) r = complete_basis(y, r, sharded);
     return r;
   }
 
@@ -239,7 +251,7 @@ struct RsvdDriver {
       const int npass = rough ? 1 : 2;
       Skinny<T> gd0 = dev.template alloc_skinny<T>(l, l);
       Skinny<T> md0 = dev.template alloc_skinny<T>(l, l);
-      const bool defer = defer_status_ && st_used_ + npass <= kStatusSlots;
+      const bool defer = defer_status_ && st_used_ + npass <= st_slots_;
       void* st_dev = defer ? (void*)((char*)st_pool_ + (size_t)st_used_ * kStatusBytes) : dev.alloc_bytes(2 * kStatusBytes);
       const double eps0 = (double)std::numeric_limits<T>::epsilon();
       for (int pass = 0; pass < npass; ++pass) {
@@ -277,7 +289,7 @@ struct RsvdDriver {
       const int npass = rough ? 1 : 2;
       const int64_t n1 = round_up((l + 1) / 2, (int64_t)4), n2 = l - n1;
       Skinny<T> gd0 = dev.template alloc_skinny<T>(l, l);
-      const bool defer = defer_status_ && st_used_ + 2 * npass <= kStatusSlots;
+      const bool defer = defer_status_ && st_used_ + 2 * npass <= st_slots_;
       void* st_dev = defer ? (void*)((char*)st_pool_ + (size_t)st_used_ * kStatusBytes) : dev.alloc_bytes(4 * kStatusBytes);
       const double eps0 = (double)std::numeric_limits<T>::epsilon();
       T* minus_one = dev.template alloc_scalar<T>(1);
@@ -326,6 +338,9 @@ struct RsvdDriver {
       if (ok && !rough) ok = dev_i[2 * (npass - 1)] <= 0.25f && dev_i[2 * (npass - 1) + 1] <= 0.25f;
       if (ok) return l;
     }
+    // host-controlled from here on: inside an optimistic run its outcome (a rank below l, columns left zero) is not
+    // covered by the deferred status records, so the whole call is repeated with the host in the loop
+    if (defer_status_) optimistic_dirty_ = true;
     const double eps = (double)std::numeric_limits<T>::epsilon();
     std::vector<double> g((size_t)l * l), mm((size_t)l * l), uu, ss, vv;
     Skinny<T> gd = dev.template alloc_skinny<T>(l, l);
@@ -435,6 +450,7 @@ struct RsvdDriver {
   // Leaves the orthonormal basis in `y` (mt x l) and returns its numerical rank.
   int64_t power_iter(const TallA<T>& a, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& y, Skinny<T>& y2) {
     qr_householder = o.qr_householder && !o.sharded;  // no cross-rank TSQR: sharded calls keep the default path
+    m_local_ = a.mt;
     PhaseTimer pt;
     Skinny<T> om = dev.template alloc_skinny<T>(a.nt, l);
     if (o.omega) {
@@ -482,6 +498,8 @@ struct RsvdDriver {
   void random_svd_tall(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
                        T* s_dev, Skinny<T>& v_tall, const std::function<void()>& emit = {}) {
     qr_householder = o.qr_householder && !o.sharded;  // no cross-rank TSQR: sharded calls keep the default path
+    m_local_ = a.mt;
+    m_global_ = -1;
     // Householder mode has no status records to defer: the body runs with the host in the loop, which also lets it
     // complete the null vectors of an exactly singular core (see random_svd_tall_body)
     const bool hh = qr_householder && !o.sharded && dev.template householder_fits<T>(l);
@@ -490,9 +508,12 @@ struct RsvdDriver {
       // (no host synchronisation inside the call).  A record that is not clean (rank deficiency, zero or
       // non-finite input, ...) repeats the computation with the host in the loop.
       const Timings saved = tm;
-      st_pool_ = dev.alloc_bytes((size_t)kStatusSlots * kStatusBytes);
+      // records: <= 2 per pass x <= 2 passes for each of the max(0, q - 3) in-loop, the final and the B^T thin-Q
+      st_slots_ = (int)std::min<int64_t>(4 * (std::max<int64_t>(0, n_iter - 3) + 2), 4096);
+      st_pool_ = dev.alloc_bytes((size_t)st_slots_ * kStatusBytes);
       st_used_ = 0;
       pending_.clear();
+      optimistic_dirty_ = false;
       defer_status_ = true;
       try {
         random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
@@ -510,10 +531,11 @@ struct RsvdDriver {
   }
 
   bool pending_clean() {
+    if (optimistic_dirty_) return false;
     if (pending_.empty()) return true;
-    int fail[kStatusSlots];
-    float min_ratio[kStatusSlots], dev_i[kStatusSlots];
-    dev.read_chol_status(st_pool_, st_used_, fail, min_ratio, dev_i);
+    std::vector<int> fail((size_t)st_used_);
+    std::vector<float> min_ratio((size_t)st_used_), dev_i((size_t)st_used_);
+    dev.read_chol_status(st_pool_, st_used_, fail.data(), min_ratio.data(), dev_i.data());
     for (const Pending& p : pending_) {
       for (int i = 0; i < p.npass * p.per_pass; ++i)
         if (fail[p.slot + i] != 0) return false;

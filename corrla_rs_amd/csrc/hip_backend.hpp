@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -89,6 +90,10 @@ class HipDev {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_block_round_kernel<double>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    {
+      std::random_device rd;
+      entropy_ = ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+    }
     split_nn_override_ = env_int("CORRLA_SPLIT_NN", 0);
     split_tn_override_ = env_int("CORRLA_SPLIT_TN", 0);
     mw_override_ = env_int("CORRLA_MW", 0);
@@ -111,6 +116,18 @@ class HipDev {
   HipDev& operator=(const HipDev&) = delete;
 
   int nranks() const { return comm_size; }
+
+  // Seed of a call that names none: the reference draws every sketch from an unseeded thread_rng
+  // (mat_utils.rs:161-175), so repeated calls must not share one Omega.  Per-context entropy (taken once, at
+  // creation) mixed with a call counter; rank_invariant (row-sharded calls: every rank must draw the SAME Omega)
+  // leaves the entropy out, so ranks that make the same sequence of calls agree.
+  uint64_t fresh_seed(bool rank_invariant) {
+    uint64_t z = (rank_invariant ? 0x5eedull : entropy_) + 0x9e3779b97f4a7c15ull * (uint64_t)(++(rank_invariant ? calls_sharded_ : calls_));
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;   // splitmix64 finaliser
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z ? z : 0x5eedull;
+  }
 
   void comm_init(const void* id128, int rank, int nranks_) {
     CORRLA_HIP(hipSetDevice(device));
@@ -243,6 +260,19 @@ class HipDev {
     CORRLA_NCCL(ncclAllReduce(p, p, count, NcclType<T>::v, ncclSum, comm, stream));
   }
   void allreduce_f64(double* p, size_t count) { allreduce<double>(p, count); }
+  // sum of one host integer over the ranks (exact in f64 up to 2^53); synchronises.  Used for rank-invariant
+  // decisions that need the global row count of a sharded matrix.
+  int64_t allreduce_sum_host(int64_t v) {
+    if (comm_size <= 1) return v;
+    if (!comm) throw Error(ST_ECOMM, "communicator not initialised");
+    double* d = alloc_f64(1);
+    double h = (double)v;
+    CORRLA_HIP(hipMemcpyAsync(d, &h, sizeof(double), hipMemcpyHostToDevice, stream));
+    CORRLA_NCCL(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, comm, stream));
+    CORRLA_HIP(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, stream));
+    sync();
+    return (int64_t)(h + 0.5);
+  }
 
   // ---- small transfers -------------------------------------------------------------------
   // device skinny (rows x cols leading block) -> host f64 column-major (ld = rows); synchronises
@@ -353,10 +383,9 @@ class HipDev {
     CORRLA_HIP(hipGetLastError());
   }
   void read_chol_status(const void* st_dev, int n, int* fail, float* min_ratio, float* dev_i) {
-    k::CholStatus h[64];
     static_assert(sizeof(k::CholStatus) == 32, "driver.hpp assumes 32-byte status records");
-    if (n > 64) throw Error(ST_EINVAL, "internal: too many status records");
-    CORRLA_HIP(hipMemcpyAsync(h, st_dev, sizeof(k::CholStatus) * n, hipMemcpyDeviceToHost, stream));
+    std::vector<k::CholStatus> h((size_t)std::max(n, 1));
+    CORRLA_HIP(hipMemcpyAsync(h.data(), st_dev, sizeof(k::CholStatus) * n, hipMemcpyDeviceToHost, stream));
     sync();
     for (int i = 0; i < n; ++i) {
       fail[i] = h[i].fail;
@@ -796,6 +825,7 @@ class HipDev {
   bool events_set_[2] = {false, false};
   static constexpr size_t kPinnedBytes = (size_t)8 << 20;
   int split_nn_override_ = 0, split_tn_override_ = 0, mw_override_ = 0, gemm_debug_flags_ = 0;
+  uint64_t entropy_ = 0, calls_ = 0, calls_sharded_ = 0;
   bool no_device_chol_ = false;
 
   static void check_grid(const dim3& g) {

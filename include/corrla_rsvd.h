@@ -69,12 +69,18 @@ typedef enum corrla_status {
  * sketches and the row-sharded entry points use the default path.  The environment variable CORRLA_QR=householder
  * sets it for every call. */
 #define CORRLA_QR_HOUSEHOLDER 0x8u
+/* opts.seed is to be used as given even when it is 0.  Without this flag seed == 0 (and opts == NULL) means "no seed":
+ * the library then draws a fresh sketch on every call, like the reference's unseeded thread_rng
+ * (mat_utils.rs:161-175); on the row-sharded entry points that fresh seed is a function of the number of seedless
+ * sharded calls made on the context only, so every rank draws the same Omega. */
+#define CORRLA_SEED_EXPLICIT 0x10u
 
 /*
  * Options block.  Zero-initialise, set struct_size = sizeof(corrla_opts).  NULL opts == defaults.
  *   seed   : seed of the device Philox4x32-10 + Box-Muller generator that replaces
  *            random_mat_normal (mat_utils.rs:161-175; the reference draws from an unseeded
  *            thread_rng, so no seed value can reproduce it -- any N(0,1) draw is equivalent).
+ *            A given seed makes the call deterministic; 0 without CORRLA_SEED_EXPLICIT = fresh draw per call.
  *   omega  : optional sketch matrix that replaces the draw at random_svd.rs:24 -- column-major
  *            n_t x l, n_t = min(m, n), leading dimension omega_ld (>= n_t), dtype of A.
  *            This is the test hook that lets the CPU oracle and the GPU share one Omega.

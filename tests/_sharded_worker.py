@@ -36,6 +36,8 @@ def main():
     k, q, p = int(d["k"]), int(d["q"]), int(d["p"])
     m = a.shape[0]
     lo, hi = rank * m // world, (rank + 1) * m // world
+    if "splits" in d.files:          # explicit (uneven) row split: splits[r] .. splits[r + 1]
+        lo, hi = int(d["splits"][rank]), int(d["splits"][rank + 1])
     for dtype in (np.float64, np.float32):
         a_loc = np.ascontiguousarray(a[lo:hi].astype(dtype))
         u, s, vt = emu_rsvd(a_loc, k, q, p, omega=omega.astype(dtype), sharded=True)

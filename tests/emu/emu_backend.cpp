@@ -61,6 +61,7 @@ class EmuDev {
  public:
   std::vector<std::unique_ptr<char[]>> blocks;
   int nranks() const { return g_nranks; }
+  uint64_t fresh_seed(bool) { return 0x5eedull; }   // the emulation stays deterministic
   void begin_call() { blocks.clear(); }
   void end_call() {}
   void sync() {}
@@ -136,6 +137,12 @@ class EmuDev {
     g_allreduce(p, count, sizeof(T) == 8);
   }
   void allreduce_f64(double* p, size_t count) { allreduce<double>(p, count); }
+  int64_t allreduce_sum_host(int64_t v) {
+    if (g_nranks <= 1) return v;
+    double h = (double)v;
+    allreduce<double>(&h, 1);
+    return (int64_t)(h + 0.5);
+  }
   template <class T>
   void download_skinny(const Skinny<T>& s, int64_t rows, int64_t cols, double* host) {
     for (int64_t j = 0; j < cols; ++j)

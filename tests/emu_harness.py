@@ -18,7 +18,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_int)
 def emu():
     global _emu
     if _emu is None:
-        path = B.build_emu()
+        path = B.build_emu(asan=os.environ.get("CORRLA_EMU_ASAN", "0") == "1")
         _emu = C.CDLL(path)
         _emu.corrla_emu_last_error.restype = C.c_char_p
     return _emu

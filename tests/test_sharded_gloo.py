@@ -47,3 +47,34 @@ def test_row_sharded_world2_matches_single_rank():
             # final thin-Q (well-conditioned input)
             n_ar = int(outs[0]["n_allreduce"])
             assert n_ar == (q + 1) + q + max(0, q - 3) + 2
+
+
+@pytest.mark.timeout(300)
+def test_row_sharded_rank_deficient_with_a_shard_shorter_than_l():
+    """A rank-deficient matrix sends every rank through the host-controlled path and `complete_basis`, which issues
+    all-reduces: the decision to enter it must be rank-invariant.  Here rank 0 holds 10 rows < l = 16 and rank 1 holds
+    40, so a test on the LOCAL row count would split the ranks (and hang the collectives); the driver uses the global
+    row count, all-reduced once."""
+    rng = np.random.default_rng(7)
+    m, n, k, q, p = 50, 30, 8, 5, 8
+    a = rng.standard_normal((m, 4)) @ rng.standard_normal((4, n))      # exact rank 4 < l = 16
+    omega = rng.standard_normal((n, k + p))
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "input.npz"), A=a, omega=omega, k=k, q=q, p=p, splits=np.array([0, 10, 50]))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "tests", "_sharded_worker.py"), td]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        ex = np.linalg.svd(a, compute_uv=False)[:k]
+        for dtype, tol in ((np.float64, 1e-9), (np.float32, 2e-4)):
+            name = np.dtype(dtype).name
+            outs = [np.load(os.path.join(td, f"out_{name}_rank{r_}.npz")) for r_ in range(2)]
+            assert int(outs[0]["hi"]) - int(outs[0]["lo"]) == 10 and int(outs[1]["hi"]) - int(outs[1]["lo"]) == 40
+            u = np.vstack([o["u"] for o in outs]).astype(np.float64)
+            s, vt = outs[0]["s"].astype(np.float64), outs[0]["vt"].astype(np.float64)
+            assert np.array_equal(outs[0]["s"], outs[1]["s"]) and np.array_equal(outs[0]["vt"], outs[1]["vt"])
+            assert np.allclose(s.ravel(), ex, atol=tol * ex[0])
+            assert np.max(np.abs(u.T @ u - np.eye(k))) < 100 * tol        # orthonormal completion across the shards
+            assert np.max(np.abs(vt @ vt.T - np.eye(k))) < 100 * tol
+            assert np.linalg.norm((u * s.ravel()) @ vt - a) <= 100 * tol * np.linalg.norm(a)
