@@ -24,8 +24,8 @@ class Opts(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("total_ms", dbl), ("sketch_ms", dbl), ("power_ms", dbl), ("qr_ms", dbl), ("project_ms", dbl),
-                ("small_svd_ms", dbl), ("finalize_ms", dbl), ("qr_passes", i32), ("reserved", i32),
-                ("sketch_kernel_ms", dbl)]
+                ("small_svd_ms", dbl), ("finalize_ms", dbl), ("qr_passes", i32), ("n_collectives", i32),
+                ("sketch_kernel_ms", dbl), ("host_enqueue_ms", dbl), ("collective_bytes", dbl)]
 
 
 # symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
@@ -38,6 +38,7 @@ def _sigs():
         "corrla_ctx_destroy": (None, [vp]),
         "corrla_ctx_synchronize": (C.c_int, [vp]),
         "corrla_ctx_get_timings": (C.c_int, [vp, C.POINTER(Timings)]),
+        "corrla_ctx_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "corrla_comm_unique_id": (C.c_int, [vp]),
         "corrla_ctx_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     }

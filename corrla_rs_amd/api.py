@@ -81,10 +81,16 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), L.UNIQUE_ID_BYTES)
         L.check(self._lib.corrla_ctx_comm_init(self._h, buf, int(rank), int(nranks)))
 
+    def comm_info(self):
+        """(rank, nranks) of the context's communicator as RCCL reports them; nranks = 0 without a communicator."""
+        r, n = C.c_int(0), C.c_int(0)
+        L.check(self._lib.corrla_ctx_comm_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
     def timings(self):
         t = L.Timings()
         L.check(self._lib.corrla_ctx_get_timings(self._h, C.byref(t)))
-        return {f: getattr(t, f) for f, _ in t._fields_ if f != "reserved"}
+        return {f: getattr(t, f) for f, _ in t._fields_}
 
     # ---- helpers -----------------------------------------------------------------------
     @staticmethod

@@ -168,7 +168,12 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
     }
     dev.copy_values_out(s_dev, k, s, host_ptrs);
   });
+  PhaseTimer fin;
+  drv.phase(drv.tm.finalize_ms, fin);  // output copies enqueued by emit()
   dev.end_call();
+  dev.phase_resolve(&drv.tm.total_ms);
+  drv.tm.n_collectives = dev.n_collectives;
+  drv.tm.collective_bytes = dev.collective_bytes;
   drv.tm.sketch_kernel_ms = dev.event_elapsed_ms(0, 1);
   if (tm_out) *tm_out = drv.tm;
 }
@@ -240,7 +245,10 @@ inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n
     dev.copy_values_out(s_dev, k, s, host_ptrs);
     dev.copy_values_out(mu.p, n, means, host_ptrs);
   });
+  PhaseTimer fin;
+  drv.phase(drv.tm.finalize_ms, fin);
   dev.end_call();
+  dev.phase_resolve(&drv.tm.total_ms);
   if (tm_out) *tm_out = drv.tm;
 }
 

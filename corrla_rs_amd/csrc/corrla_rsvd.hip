@@ -151,6 +151,14 @@ CORRLA_API void corrla_ctx_destroy(corrla_ctx* ctx) { delete ctx; }
 CORRLA_API corrla_status corrla_ctx_synchronize(corrla_ctx* ctx) {
   return guarded([&] { need(ctx)->dev.sync(); });
 }
+CORRLA_API corrla_status corrla_ctx_comm_info(corrla_ctx* ctx, int* rank, int* nranks) {
+  return guarded([&] {
+    corrla_ctx* c = need(ctx);
+    if (!rank || !nranks) throw Error(ST_EINVAL, "NULL argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->dev.comm_info(rank, nranks);
+  });
+}
 CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);
@@ -164,8 +172,10 @@ CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings*
     out->small_svd_ms = t.small_svd_ms;
     out->finalize_ms = t.finalize_ms;
     out->qr_passes = t.qr_passes;
-    out->reserved = 0;
+    out->n_collectives = t.n_collectives;
+    out->collective_bytes = t.collective_bytes;
     out->sketch_kernel_ms = t.sketch_kernel_ms;
+    out->host_enqueue_ms = t.host_enqueue_ms;
   });
 }
 

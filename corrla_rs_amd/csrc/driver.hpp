@@ -102,8 +102,13 @@ struct RunOpts {
 };
 
 struct Timings {
+  // DEVICE time of each phase: elapsed time between events recorded on the context's stream at the phase boundaries
+  // (Dev::phase_mark), resolved after the call has completed -- no synchronisation inside the call
   double total_ms = 0, sketch_ms = 0, power_ms = 0, qr_ms = 0, project_ms = 0, small_svd_ms = 0, finalize_ms = 0;
+  double host_enqueue_ms = 0;  // host wall clock spent enqueueing the call (the host runs ahead of the device)
   int qr_passes = 0;
+  int n_collectives = 0;        // all-reduces issued by this call on this rank (row-sharded entry points)
+  double collective_bytes = 0;  // payload bytes of those all-reduces
   // breakdown of qr_ms (only filled when phase profiling is on): Gram GEMM, D2H + analysis, host Cholesky /
   // inverse, H2D + apply GEMM
   double qr_gram_ms = 0, qr_down_ms = 0, qr_host_ms = 0, qr_apply_ms = 0;
@@ -203,7 +208,7 @@ struct RsvdDriver {
       PhaseTimer qt0;
       dev.householder_thin_q(y, tmp);
       ++tm.qr_passes;
-      phase(tm.qr_gram_ms, qt0);
+      subphase(tm.qr_gram_ms, qt0);
       return l;
     }
     int64_t r = orthonormalize_core(y, tmp, sharded, rough);
@@ -268,13 +273,13 @@ struct RsvdDriver {
         // computation through the host-controlled path below
         pending_.push_back({st_used_, npass, rough, 1});
         st_used_ += npass;
-        phase(tm.qr_gram_ms, qt0);
+        subphase(tm.qr_gram_ms, qt0);
         return l;
       }
       int fail[2] = {0, 0};
       float min_ratio[2], dev_i[2];
       dev.read_chol_status(st_dev, npass, fail, min_ratio, dev_i);
-      phase(tm.qr_gram_ms, qt0);
+      subphase(tm.qr_gram_ms, qt0);
       for (int pass = 0; pass < npass; ++pass)
         if (fail[pass] == 3) throw Error(ST_ENUMERIC, "non-finite Gram matrix in orthonormalisation");
       if (fail[0] == 2) return 0;  // Y is the zero matrix
@@ -323,13 +328,13 @@ struct RsvdDriver {
       if (defer) {
         pending_.push_back({st_used_, npass, rough, 2});
         st_used_ += 2 * npass;
-        phase(tm.qr_gram_ms, qt0);
+        subphase(tm.qr_gram_ms, qt0);
         return l;
       }
       int fail[4] = {0, 0, 0, 0};
       float min_ratio[4], dev_i[4];
       dev.read_chol_status(st_dev, 2 * npass, fail, min_ratio, dev_i);
-      phase(tm.qr_gram_ms, qt0);
+      subphase(tm.qr_gram_ms, qt0);
       bool ok = true;
       for (int i = 0; i < 2 * npass; ++i) {
         if (fail[i] == 3) throw Error(ST_ENUMERIC, "non-finite Gram matrix in orthonormalisation");
@@ -359,7 +364,7 @@ struct RsvdDriver {
       PhaseTimer qt;
       dev.gemm_nn(as_rowmajor_transposed(y, r), yv, gv, kNone);
       if (sharded) dev.allreduce(gd.p, (size_t)gd.ld * (size_t)gd.cols_alloc);
-      phase(tm.qr_gram_ms, qt);
+      subphase(tm.qr_gram_ms, qt);
       ++tm.qr_passes;
       if (series_next) {
         Skinny<T> mv = md.view_cols(r);
@@ -369,7 +374,7 @@ struct RsvdDriver {
         dev.gemm_tn(as_rowmajor_transposed(y, r), mv, out, kNone);
         if (r < l) dev.zero_cols(tmp, r, l);
         std::swap(y.p, tmp.p);
-        phase(tm.qr_apply_ms, qt);
+        subphase(tm.qr_apply_ms, qt);
         break;
       }
       dev.download_skinny(gv, r, r, g.data());
@@ -385,7 +390,7 @@ struct RsvdDriver {
         r = 0;
         break;
       }
-      tm.qr_down_ms += qt.lap();
+      subphase(tm.qr_down_ms, qt);
       if (dev_i <= 16.0 * eps) break;  // already orthonormal at working precision
       const bool near_i = dev_i <= 0.25;
       int64_t r_new = r;
@@ -427,7 +432,7 @@ struct RsvdDriver {
         small::triu_inverse((int)r, rr.data(), (int)r);
         std::copy(rr.begin(), rr.end(), mm.begin());
       }
-      tm.qr_host_ms += qt.lap();
+      subphase(tm.qr_host_ms, qt);
       // Y[:, :r_new] <- Y[:, :r] * M (r x r_new); columns >= r_new become zero.
       Skinny<T> mv = md.view_cols(r_new);
       mv.rows = r;
@@ -437,7 +442,7 @@ struct RsvdDriver {
       if (r_new < l) dev.zero_cols(tmp, r_new, l);
       std::swap(y.p, tmp.p);
       r = r_new;
-      phase(tm.qr_apply_ms, qt);
+      subphase(tm.qr_apply_ms, qt);
       if (clean && (near_i || rough)) break;
       // predicted orthogonality defect of the pass just applied: ~ l * eps * kappa^2 <= l * eps / min pivot ratio
       if (clean && fails == 0 && r == l && 4.0 * (double)l * eps / std::max(min_ratio_last, 1e-300) <= series_max_e)
@@ -525,6 +530,7 @@ struct RsvdDriver {
       if (emit) emit();
       if (pending_clean()) return;
       tm = saved;
+      dev.phase_forget();  // the abandoned run still counts in total_ms, not in the phase slots
     }
     random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
     if (emit) emit();
@@ -591,11 +597,19 @@ struct RsvdDriver {
     // sign convention (the reference fixes none): largest-magnitude component of every v_i positive
     dev.fix_signs(v_tall, u_tall, k);
     phase(tm.finalize_ms, pt);
-    tm.total_ms += total.lap();
+    tm.host_enqueue_ms += total.lap();
   }
 
+  // everything enqueued since the previous mark belongs to `slot` (device time, resolved after the call)
   void phase(double& slot, PhaseTimer& pt) {
     if (profile_phases) dev.sync();
+    (void)pt.lap();
+    dev.phase_mark(&slot);
+  }
+  // nested breakdown of the orthonormalisation (debugging aid): host wall clock, only with synchronised phases
+  void subphase(double& slot, PhaseTimer& pt) {
+    if (!profile_phases) return;
+    dev.sync();
     slot += pt.lap();
   }
 };

@@ -57,6 +57,8 @@ class HipDev {
   hipStream_t stream = nullptr;
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_size = 1;
+  int n_collectives = 0;        // since begin_call
+  double collective_bytes = 0;
 
   explicit HipDev(int dev_ordinal) : device(dev_ordinal) {
     int count = 0;
@@ -110,6 +112,7 @@ class HipDev {
     if (pinned_) (void)hipHostFree(pinned_);
     for (auto& e : events_)
       if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_pool_) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
   HipDev(const HipDev&) = delete;
@@ -142,11 +145,26 @@ class HipDev {
     comm_rank = rank;
     comm_size = nranks_;
   }
+  // what RCCL itself reports for the communicator (not what the caller asked for)
+  void comm_info(int* rank_out, int* nranks_out) {
+    if (!comm) {
+      *rank_out = 0;
+      *nranks_out = 0;
+      return;
+    }
+    CORRLA_NCCL(ncclCommUserRank(comm, rank_out));
+    CORRLA_NCCL(ncclCommCount(comm, nranks_out));
+  }
 
   // ---- memory ----------------------------------------------------------------------------
   void begin_call() {
     CORRLA_HIP(hipSetDevice(device));
     events_set_[0] = events_set_[1] = false;
+    n_collectives = 0;
+    collective_bytes = 0;
+    marks_.clear();
+    ev_used_ = 0;
+    phase_mark(nullptr);  // start of the call
     for (auto& c : chunks_) c.used = 0;
     // zero pool: the part the previous call used is cleared by ONE memset per chunk (capped), instead of one
     // small memset per workspace allocation
@@ -258,6 +276,8 @@ class HipDev {
     if (comm_size <= 1 && !(comm && env_int("CORRLA_FORCE_ALLREDUCE", 0))) return;
     if (!comm) throw Error(ST_ECOMM, "communicator not initialised");
     CORRLA_NCCL(ncclAllReduce(p, p, count, NcclType<T>::v, ncclSum, comm, stream));
+    ++n_collectives;
+    collective_bytes += (double)count * sizeof(T);
   }
   void allreduce_f64(double* p, size_t count) { allreduce<double>(p, count); }
   // sum of one host integer over the ranks (exact in f64 up to 2^53); synchronises.  Used for rank-invariant
@@ -269,6 +289,8 @@ class HipDev {
     double h = (double)v;
     CORRLA_HIP(hipMemcpyAsync(d, &h, sizeof(double), hipMemcpyHostToDevice, stream));
     CORRLA_NCCL(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, comm, stream));
+    ++n_collectives;
+    collective_bytes += sizeof(double);
     CORRLA_HIP(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, stream));
     sync();
     return (int64_t)(h + 0.5);
@@ -778,6 +800,42 @@ class HipDev {
     CORRLA_HIP(hipGetLastError());
   }
 
+  // ---- per-phase device times (corrla_timings) ------------------------------------------------------------
+  // An event is recorded on the compute stream at every phase boundary; after the call has completed,
+  // phase_resolve() adds the elapsed device time between consecutive events to the slot named at the later one.
+  void phase_mark(double* slot) {
+    if (ev_used_ == ev_pool_.size()) {
+      hipEvent_t e;
+      CORRLA_HIP(hipEventCreate(&e));
+      ev_pool_.push_back(e);
+    }
+    hipEvent_t e = ev_pool_[ev_used_++];
+    CORRLA_HIP(hipEventRecord(e, stream));
+    marks_.push_back({e, slot});
+  }
+  void phase_forget() {
+    for (auto& m_ : marks_) m_.slot = nullptr;
+  }
+  // call after end_call(); *total (optional) receives first-mark -> last-mark
+  void phase_resolve(double* total) {
+    for (size_t i = 1; i < marks_.size(); ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, marks_[i - 1].ev, marks_[i].ev) != hipSuccess) {
+        (void)hipGetLastError();
+        continue;
+      }
+      if (marks_[i].slot) *marks_[i].slot += (double)ms;
+    }
+    if (total && marks_.size() >= 2) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, marks_.front().ev, marks_.back().ev) == hipSuccess)
+        *total = (double)ms;
+      else
+        (void)hipGetLastError();
+    }
+    marks_.clear();
+  }
+
   // hipEvents on the compute stream around a kernel sequence of the current call (read after end_call)
   void event_mark(int i) {
     CORRLA_HIP(hipEventRecord(events_[i], stream));
@@ -823,6 +881,13 @@ class HipDev {
   void* pinned_ = nullptr;  // staging for the small l x l transfers
   hipEvent_t events_[2] = {nullptr, nullptr};
   bool events_set_[2] = {false, false};
+  struct PhaseMark {
+    hipEvent_t ev;
+    double* slot;
+  };
+  std::vector<hipEvent_t> ev_pool_;
+  size_t ev_used_ = 0;
+  std::vector<PhaseMark> marks_;
   static constexpr size_t kPinnedBytes = (size_t)8 << 20;
   int split_nn_override_ = 0, split_tn_override_ = 0, mw_override_ = 0, gemm_debug_flags_ = 0;
   uint64_t entropy_ = 0, calls_ = 0, calls_sharded_ = 0;

@@ -93,20 +93,23 @@ typedef struct corrla_opts {
   int64_t omega_ld;
 } corrla_opts;
 
-/* Phase timings of the last rsvd call on a context, milliseconds (host wall clock around
- * stream-synchronised phases; replaces the SystemTime prints of random_svd.rs:125-140). */
+/* Phase timings of the last rsvd / pca call on a context, milliseconds of DEVICE time: hipEvents are recorded on the
+ * context's stream at the phase boundaries and resolved after the call has completed (no synchronisation inside the
+ * call; replaces the SystemTime prints of random_svd.rs:125-140).  The phases add up to total_ms. */
 typedef struct corrla_timings {
-  double total_ms;
-  double sketch_ms;     /* Y = A*Omega                       random_svd.rs:31      */
+  double total_ms;      /* first to last event of the call */
+  double sketch_ms;     /* Omega draw, Y = A*Omega            random_svd.rs:24,31   */
   double power_ms;      /* q x {Z = A^T Y, Y = A Z, norm}    random_svd.rs:35-56   */
   double qr_ms;         /* thin-Q orthonormalisations        random_svd.rs:38,57   */
   double project_ms;    /* B = Q^T A                         random_svd.rs:80      */
   double small_svd_ms;  /* svd of the l-wide core            random_svd.rs:89      */
-  double finalize_ms;   /* U = Q*Ut, output copies           random_svd.rs:92-109  */
+  double finalize_ms;   /* U = Q*Ut, signs, output copies    random_svd.rs:92-109  */
   int32_t qr_passes;    /* Gram/whitening passes used by all orthonormalisations */
-  int32_t reserved;
+  int32_t n_collectives; /* all-reduces this rank issued during the call (row-sharded entry points; else 0) */
   double sketch_kernel_ms; /* device time of the sketch GEMM launch(es) of this call: hipEvents recorded on the
                               context's stream around Y = A*Omega (no extra synchronisation) */
+  double host_enqueue_ms;  /* host wall clock spent enqueueing the call: the host runs ahead of the device */
+  double collective_bytes; /* payload bytes of those all-reduces (n x l factors, l x l Gram matrices, scalars) */
 } corrla_timings;
 
 /* ---- library / context ------------------------------------------------------------- */
@@ -125,6 +128,9 @@ CORRLA_API corrla_status corrla_ctx_create(int device_ordinal, corrla_ctx** out)
 CORRLA_API void corrla_ctx_destroy(corrla_ctx* ctx);
 CORRLA_API corrla_status corrla_ctx_synchronize(corrla_ctx* ctx);
 CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out);
+/* Rank and size of the context's RCCL communicator as RCCL reports them (ncclCommUserRank / ncclCommCount);
+ * nranks = 0 when corrla_ctx_comm_init has not been called. */
+CORRLA_API corrla_status corrla_ctx_comm_info(corrla_ctx* ctx, int* rank, int* nranks);
 
 /* ---- the hot path: random_svd -------------------------------------------------------
  * Replaces  pub fn random_svd<T>(a_mat: MatRef<T>, omega_rank, n_iter, n_oversamples)

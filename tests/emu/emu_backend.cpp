@@ -60,12 +60,17 @@ inline double normal_from_index<double>(uint64_t i, uint64_t s) { return normal_
 class EmuDev {
  public:
   std::vector<std::unique_ptr<char[]>> blocks;
+  int n_collectives = 0;
+  double collective_bytes = 0;
   int nranks() const { return g_nranks; }
   uint64_t fresh_seed(bool) { return 0x5eedull; }   // the emulation stays deterministic
   void begin_call() { blocks.clear(); }
   void end_call() {}
   void sync() {}
   void event_mark(int) {}
+  void phase_mark(double*) {}
+  void phase_resolve(double*) {}
+  void phase_forget() {}
   double event_elapsed_ms(int, int) { return 0.0; }
   void* alloc_bytes(size_t bytes) {
     blocks.emplace_back(new char[bytes + 64]);
@@ -135,6 +140,8 @@ class EmuDev {
     if (g_nranks <= 1) return;
     if (!g_allreduce) throw Error(ST_ECOMM, "emu: no allreduce callback");
     g_allreduce(p, count, sizeof(T) == 8);
+    ++n_collectives;
+    collective_bytes += (double)count * sizeof(T);
   }
   void allreduce_f64(double* p, size_t count) { allreduce<double>(p, count); }
   int64_t allreduce_sum_host(int64_t v) {

@@ -35,9 +35,70 @@ def test_header_symbols_all_exported_and_bound(lib):
         assert s in syms, f"{s} bound in _lib.py but not declared in the header"
 
 
-def test_struct_layouts_match_header(lib):
-    assert C.sizeof(L.Opts) == 32          # u32 u32 u64 ptr i64
-    assert C.sizeof(L.Timings) == 7 * 8 + 8 + 8
+def test_header_compiles_as_c_and_struct_layouts_match_ctypes(tmp_path):
+    """include/corrla_rsvd.h is a C header: compile it with a C compiler (no C++), and compare sizeof / offsetof of the
+    two structs that cross the boundary with their ctypes mirrors."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c",
+                           os.path.join(hdr, "corrla_rsvd.h")])
+    fields = {"corrla_opts": [f for f, _ in L.Opts._fields_], "corrla_timings": [f for f, _ in L.Timings._fields_]}
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "corrla_rsvd.h"', "int main(void) {"]
+    for st, fl in fields.items():
+        src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for f in fl:
+            src.append(f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    src += ["  return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I" + hdr, str(c), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for st, cls in (("corrla_opts", L.Opts), ("corrla_timings", L.Timings)):
+        assert int(out[st]) == C.sizeof(cls), st
+        for f, _ in cls._fields_:
+            assert int(out[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
+
+
+def _c_kind(t):
+    """coarse ABI class of a C parameter / return type"""
+    t = t.strip()
+    if "*" in t:
+        return "ptr"
+    t = re.sub(r"\bconst\b", "", t).strip()
+    return {"int64_t": "i64", "uint64_t": "u64", "int": "int", "float": "f32", "double": "f64", "void": "void",
+            "corrla_status": "int"}[t]
+
+
+def _ctypes_kind(t):
+    if t is None:
+        return "void"
+    if t in (C.c_void_p, C.c_char_p) or isinstance(t, type) and issubclass(t, C._Pointer):
+        return "ptr"
+    return {C.c_int64: "i64", C.c_uint64: "u64", C.c_int: "int", C.c_float: "f32", C.c_double: "f64"}[t]
+
+
+def test_prototypes_match_the_ctypes_table():
+    """Every prototype of the header against corrla_rs_amd/_lib.SIGNATURES: return type, parameter count and the ABI
+    class (pointer / int / int64 / uint64 / float / double) of every parameter in order -- an argument-order or width
+    drift between the header and the hand-written ctypes table fails here (names alone do not)."""
+    import subprocess
+    txt = subprocess.check_output(["gcc", "-E", "-P", "-x", "c", os.path.join(ROOT, "include", "corrla_rsvd.h")], text=True)
+    txt = re.sub(r"__attribute__\s*\(\(.*?\)\)", "", txt)
+    protos = re.findall(r"([A-Za-z_][\w\s\*]*?)\b(corrla_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt)
+    seen = {}
+    for ret, name, args in protos:
+        ret = ret.replace("extern", "").strip()
+        params = [] if args.strip() in ("", "void") else [a.strip() for a in args.split(",")]
+        kinds = []
+        for prm in params:
+            m = re.match(r"(.*?)(\w+)$", prm)        # strip the parameter name
+            kinds.append(_c_kind(m.group(1) if m and m.group(1).strip() else prm))
+        seen[name] = (_c_kind(ret), kinds)
+    assert set(seen) == set(L.SIGNATURES)
+    for name, (res, argtypes) in L.SIGNATURES.items():
+        want = (_ctypes_kind(res), [_ctypes_kind(a) for a in argtypes])
+        assert seen[name] == want, (name, seen[name], want)
 
 
 def test_version_and_error_strings(lib):

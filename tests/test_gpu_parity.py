@@ -103,6 +103,29 @@ def test_fill_normal_matches_host_restatement(ctx, torch):
     assert abs(big.mean().item()) < 3e-3 and abs(big.std().item() - 1) < 3e-3
 
 
+def test_fill_normal_distribution_on_the_gpu(ctx, torch):
+    """random_mat_normal draws i.i.d. N(0,1) (mat_utils.rs:161-175, rand_distr StandardNormal).  Kolmogorov-Smirnov
+    test of the GPU generator's OUTPUT (not of the host restatement) against the normal CDF, both dtypes, plus
+    moments, tail mass and the absence of correlation between neighbouring counters / rows / seeds."""
+    from scipy import stats
+    for dt in (torch.float32, torch.float64):
+        t = torch.empty((4096, 512), dtype=dt, device="cuda")
+        ctx.fill_normal(t, seed=12345)
+        x = t.cpu().numpy().astype(np.float64)
+        ks = stats.kstest(x.ravel()[:: 2], "norm")            # 1M samples
+        assert ks.pvalue > 1e-3, (dt, ks)
+        assert abs(x.mean()) < 4 / np.sqrt(x.size) and abs(x.var() - 1) < 6 * np.sqrt(2.0 / x.size)
+        assert abs(stats.skew(x.ravel())) < 0.01 and abs(stats.kurtosis(x.ravel())) < 0.02
+        frac3 = np.mean(np.abs(x) > 3.0)
+        assert abs(frac3 - 0.0026998) < 2.5e-4                # two-sided 3-sigma tail mass
+        # neighbouring counters (columns), neighbouring rows, and a different seed: uncorrelated
+        assert abs(np.mean(x[:, :-1] * x[:, 1:])) < 5 / np.sqrt(x.size)
+        assert abs(np.mean(x[:-1] * x[1:])) < 5 / np.sqrt(x.size)
+        t2 = torch.empty_like(t)
+        ctx.fill_normal(t2, seed=12346)
+        assert abs(np.mean(x * t2.cpu().numpy())) < 5 / np.sqrt(x.size)
+
+
 # ---- random_svd vs the oracle on the golden fixtures ---------------------------------------------
 def _parity(ctx, a, k, q, p, omega, dtype, s_rtol, rec_rtol, device_path=False):
     a = np.asarray(a, dtype=dtype)
