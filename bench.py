@@ -123,7 +123,8 @@ def cpu_baseline(a_dev, k, q, p, l, sample_rows):
         pass
     threads = min(CPU_THREADS, avail)
     with threadpool_limits(limits=threads):
-        orc.random_svd(a[:1024], k, q, p, omega=omega)  # warm the BLAS threads
+        w = a[:2048, :min(n, 1024)]                                    # warm the BLAS threads on a small tall block
+        orc.random_svd(w, min(k, 64), 1, p, omega=omega[:w.shape[1], :min(min(k, 64) + p, w.shape[1])])
         t0 = time.perf_counter()
         uo, so, vto = orc.random_svd(a, k, q, p, omega=omega)
         dt = time.perf_counter() - t0

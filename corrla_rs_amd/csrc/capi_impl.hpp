@@ -154,13 +154,26 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
   const int64_t l = std::min<int64_t>(rank + n_oversamples, ta.nt);  // random_svd.rs:77
   if (ro.omega && ro.omega_ld < ta.nt) throw Error(ST_EINVAL, "omega_ld < min(m, n)");
   RsvdDriver<Dev, T> drv(dev, profile);
-  Skinny<T> ut = dev.template alloc_skinny<T>(ta.mt, k);
+  // Tall input, device pointers: the m x k factor U is produced directly in the caller's buffer (column-major, ldu)
+  // -- no staging copy of the largest output.
+  const bool u_in_place = !fat && !host_ptrs;
+  Skinny<T> ut;
+  if (u_in_place) {
+    ut.p = u;
+    ut.rows = ta.mt;
+    ut.cols = k;
+    ut.ld = ldu;
+    ut.cols_alloc = k;
+    ut.external = true;
+  } else {
+    ut = dev.template alloc_skinny<T>(ta.mt, k);
+  }
   Skinny<T> vtall = dev.template alloc_skinny<T>(ta.nt, k);
   T* s_dev = dev.template alloc_scalar<T>((int)k);
   drv.random_svd_tall(ta, k, l, n_iter, ro, ut, s_dev, vtall, [&] {
     // random_svd.rs:96-109: tall -> (U, S, V^T); fat -> (V, S, U^T) of the transposed problem
     if (!fat) {
-      dev.copy_out(ut, k, u, ldu, /*transpose=*/false, host_ptrs);
+      if (!u_in_place) dev.copy_out(ut, k, u, ldu, /*transpose=*/false, host_ptrs);
       dev.copy_out(vtall, k, vt, ldvt, /*transpose=*/true, host_ptrs);
     } else {
       dev.copy_out(vtall, k, u, ldu, false, host_ptrs);

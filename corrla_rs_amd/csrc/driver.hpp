@@ -50,6 +50,9 @@ template <class T>
 struct Skinny {
   T* p = nullptr;
   int64_t rows = 0, cols = 0, ld = 0, cols_alloc = 0;
+  // a caller's buffer used in place as the destination of a product: only `cols` columns exist (no zero padding
+  // beyond them), so kernels must not write past column cols - 1 and nothing may use it as a padded operand
+  bool external = false;
   Skinny view_cols(int64_t c) const {
     Skinny s = *this;
     s.cols = c;
@@ -481,13 +484,16 @@ struct RsvdDriver {
         phase(tm.qr_ms, pt);
       }
       at_times(a, y, z, kNone, o.sharded);  // :42-46
-      a_times(a, z, y, kNone);              // :47-51
-      dev.sumsq(y, ss_dev);                 // :54 norm_l2 (Frobenius)
-      if (o.sharded) dev.allreduce_f64(ss_dev, 1);
+      // :53-55 rescales Y by 1 / ||Y||_F after every iteration so that nothing overflows; the span -- all the final
+      // thin-Q keeps -- does not depend on WHICH positive factor is used.  Here the factor is 1 / ||Z||_F applied to
+      // Z (n x l, a few hundred KB, replicated on every rank) BEFORE Y = A Z: Y comes out at ||A Z^|| <= sigma_1
+      // instead of sigma_1^3 (a wider safe range than the reference's own), no pass over the m-sized Y is spent on
+      // the norm or the scaling (two sweeps of 3.2 GB each per iteration at 10^7 x 80), and sharded runs need no
+      // scalar all-reduce (Z is already all-reduced).
+      dev.sumsq(z, ss_dev);
       dev.rsqrt_scalar(ss_dev, inv_dev);
-      // :53-55.  Applied to Y itself, like the reference: folding 1/||Y|| into the NEXT product's epilogue would
-      // form A^T Y unscaled first and overflow f32 a factor sigma_1 earlier than the reference does.
-      dev.scale_inplace(y, inv_dev);
+      dev.scale_inplace(z, inv_dev);
+      a_times(a, z, y, kNone);              // :47-51
     }
     phase(tm.power_ms, pt);
     int64_t r = orthonormalize(y, y2, o.sharded);  // :57
@@ -514,7 +520,7 @@ struct RsvdDriver {
       // non-finite input, ...) repeats the computation with the host in the loop.
       const Timings saved = tm;
       // records: <= 2 per pass x <= 2 passes for each of the max(0, q - 3) in-loop, the final and the B^T thin-Q
-      st_slots_ = (int)std::min<int64_t>(4 * (std::max<int64_t>(0, n_iter - 3) + 2), 4096);
+      st_slots_ = (int)std::min<int64_t>(4 * (std::max<int64_t>(0, n_iter - 3) + 2) + 1, 4096);  // + the core SVD's
       st_pool_ = dev.alloc_bytes((size_t)st_slots_ * kStatusBytes);
       st_used_ = 0;
       pending_.clear();
@@ -555,8 +561,10 @@ struct RsvdDriver {
   void random_svd_tall_body(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
                             T* s_dev, Skinny<T>& v_tall) {
     PhaseTimer total;
-    Skinny<T> q = dev.template alloc_skinny<T>(a.mt, l);
-    Skinny<T> q2 = dev.template alloc_skinny<T>(a.mt, l);
+    // both are written by a product before anything reads them (q: the sketch; q2: the first Y * R^-1)
+    const bool hh_tmp = qr_householder && !o.sharded;  // the Householder path stores reflectors in q2: keep it zero-filled
+    Skinny<T> q = dev.template alloc_skinny_out<T>(a.mt, l);
+    Skinny<T> q2 = hh_tmp ? dev.template alloc_skinny<T>(a.mt, l) : dev.template alloc_skinny_out<T>(a.mt, l);
     power_iter(a, l, n_iter, o, q, q2);  // :76-77
     PhaseTimer pt;
     // B^T = A^T Q  (n x l)                                                           :80
@@ -571,15 +579,27 @@ struct RsvdDriver {
     dev.copy_skinny(bt, qb);
     orthonormalize(qb, qb2, false);
     phase(tm.qr_ms, pt);
-    Skinny<T> cd = dev.template alloc_skinny<T>(l, l);
-    dev.gemm_nn(as_rowmajor_transposed(qb, l), bt, cd, kNone);
+    // The core is formed TRANSPOSED, C^T = B Qb = (Qb^T B^T)^T: C is the triangular factor R of B^T = Qb R (up to
+    // rounding), and one-sided Jacobi on the columns of R^T converges in far fewer sweeps than on the columns of R
+    // when the spectrum decays (l = 138, sigma_i = 0.9^i: 9 sweeps against 22; flat spectra: the same 7) -- the
+    // Drmac-Veselic preconditioning, free here because the QR has just been done.
+    // C^T = Vc S Uc^T, so the roles of the two factors swap: small_svd(X) returns (V_X -> first, U_X -> second).
+    Skinny<T> ct = dev.template alloc_skinny<T>(l, l);
+    dev.gemm_nn(as_rowmajor_transposed(bt, l), qb, ct, kNone);
     Skinny<T> m1 = dev.template alloc_skinny<T>(l, k);  // U~[:, :k] = Vc[:, :k]
     Skinny<T> m2 = dev.template alloc_skinny<T>(l, k);  // Uc[:, :k]
-    dev.small_svd(cd, l, k, m1, m2, s_dev);
+    void* svd_st = nullptr;
+    if (defer_status_ && st_used_ + 1 <= st_slots_) {
+      // kernels that run a fixed number of sweeps report convergence here; checked with the Cholesky records
+      svd_st = (void*)((char*)st_pool_ + (size_t)st_used_ * kStatusBytes);
+      pending_.push_back({st_used_, 1, true, 1});
+      st_used_ += 1;
+    }
+    dev.small_svd(ct, l, k, m2, m1, s_dev, svd_st);
     if (!defer_status_) {
       // Exactly singular core (rank-deficient or zero input; only reachable through the host-controlled path): the
-      // left vectors w_j / sigma_j of its null triplets do not exist.  Give them an orthonormal completion, like
-      // the arbitrary-but-orthonormal null vectors of the reference's full SVD.
+      // vectors w_j / sigma_j of its null triplets (here: columns of Vc, the Jacobi runs on C^T) do not exist.  Give
+      // them an orthonormal completion, like the arbitrary-but-orthonormal null vectors of the reference's full SVD.
       std::vector<T> sh((size_t)k);
       dev.copy_values_out(s_dev, k, sh.data(), /*dst_is_host=*/true);
       // numerically null: below eps * 1e-3 of the largest singular value nothing of the direction survives the
@@ -587,15 +607,17 @@ struct RsvdDriver {
       const T null_tol = (T)(1e-3 * (double)std::numeric_limits<T>::epsilon()) * sh[0];
       int64_t nz = 0;
       while (nz < k && sh[(size_t)nz] > null_tol) ++nz;
-      if (nz < k) complete_basis(m2, nz, false);
+      if (nz < k) complete_basis(m1, nz, false);
     }
     phase(tm.small_svd_ms, pt);
-    // U = Q * U~[:, :k]                                                               :92, :96-109
-    dev.gemm_tn(as_rowmajor_transposed(q, l), m1, u_tall, kNone);
     // V = Qb * Uc[:, :k]
     dev.gemm_tn(as_rowmajor_transposed(qb, l), m2, v_tall, kNone);
-    // sign convention (the reference fixes none): largest-magnitude component of every v_i positive
-    dev.fix_signs(v_tall, u_tall, k);
+    // sign convention (the reference fixes none): largest-magnitude component of every v_i positive.  The signs only
+    // depend on V (short side), so they are folded into the l x k factor U~ BEFORE the tall product: U needs no
+    // sign pass and can be written straight into the caller's buffer.
+    dev.fix_signs(v_tall, m1, k);
+    // U = Q * U~[:, :k]                                                               :92, :96-109
+    dev.gemm_tn(as_rowmajor_transposed(q, l), m1, u_tall, kNone);
     phase(tm.finalize_ms, pt);
     tm.host_enqueue_ms += total.lap();
   }

@@ -18,6 +18,7 @@
 #include "driver.hpp"
 #include "hip_kernels.hpp"
 #include "tsqr_kernels.hpp"
+#include "jacobi_mc_kernels.hpp"
 
 namespace corrla {
 
@@ -84,6 +85,8 @@ class HipDev {
     set_ring_attrs<double, 18>();
     set_tsqr_attrs<float>();
     set_tsqr_attrs<double>();
+    set_jmc_attrs<float>();
+    set_jmc_attrs<double>();
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<float>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<double>,
@@ -100,6 +103,8 @@ class HipDev {
     split_tn_override_ = env_int("CORRLA_SPLIT_TN", 0);
     mw_override_ = env_int("CORRLA_MW", 0);
     no_device_chol_ = env_int("CORRLA_HOST_CHOL", 0) != 0;
+    jmc_min_l_ = env_int("CORRLA_JMC_MIN_L", 145);  // l <= 144: the register-resident ring kernel + replay is as fast
+    jmc_max_b_ = std::min(32, std::max(2, env_int("CORRLA_JMC_MAX_B", 24)));
     gemm_debug_flags_ = env_int("CORRLA_GEMM_DEBUG", 0);  // timing-only ablations, results are wrong
   }
   ~HipDev() {
@@ -236,6 +241,27 @@ class HipDev {
     s.cols_alloc = col_blocking(cols).cols_alloc;
     const size_t bytes = (size_t)s.ld * (size_t)s.cols_alloc * sizeof(T);
     s.p = (T*)alloc_zeroed(bytes);
+    return s;
+  }
+  // a skinny matrix that a product is about to overwrite completely (every allocated column, rows [0, rows)): only
+  // the padding rows [rows, ld) are cleared instead of the whole buffer (four m x l work matrices of a 10^7-row call
+  // are 12.8 GB of memset otherwise)
+  template <class T>
+  Skinny<T> alloc_skinny_out(int64_t rows, int64_t cols) {
+    Skinny<T> s;
+    s.rows = rows;
+    s.cols = cols;
+    s.ld = round_up(std::max<int64_t>(rows, 1), kLdPad);
+    s.cols_alloc = col_blocking(cols).cols_alloc;
+    const size_t bytes = (size_t)s.ld * (size_t)s.cols_alloc * sizeof(T);
+    if (bytes < ((size_t)4 << 20)) {
+      s.p = (T*)alloc_zeroed(bytes);
+      return s;
+    }
+    s.p = (T*)alloc_bytes(bytes);
+    if (s.ld > rows)
+      CORRLA_HIP(hipMemset2DAsync(s.p + rows, (size_t)s.ld * sizeof(T), 0, (size_t)(s.ld - rows) * sizeof(T), (size_t)s.cols_alloc,
+                                  stream));
     return s;
   }
   double* alloc_f64(int n) {
@@ -499,6 +525,143 @@ class HipDev {
     CORRLA_HIP(hipGetLastError());
   }
 
+  template <class T>
+  void set_jmc_attrs() {
+    const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 1>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 2>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 3>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 4>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 5>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 6>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 7>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 8>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 9>, attr, 160 * 1024));
+  }
+
+  // ---- multi-workgroup block Jacobi (jacobi_mc_kernels.hpp) ------------------------------------------------
+  // geometry for an l x l core: chunk rows NC, workgroups NP, block width b (even, <= 32); false when it does not fit
+  template <class T>
+  bool jmc_geometry(int64_t l, int* nc_out, int* np_out, int* b_out) const {
+    if (l < 2 || l > 288) return false;
+    const int nc = (int)((l + 31) / 32);
+    auto width = [&](int np_) {
+      int bb = (int)((l + 2 * np_ - 1) / (2 * np_));
+      return bb + (bb & 1);
+    };
+    int np = env_int("CORRLA_JMC_NP", 0);
+    if (np <= 0) {
+      // fewest workgroups whose block pair fits one CU (<= 32 processors, LDS): fewer, larger steps per sweep
+      np = 2;
+      while (np < 128 && (width(np) > jmc_max_b_ || k::jmc_lds_bytes(nc, width(np), sizeof(T)) > (size_t)160 * 1024)) ++np;
+    }
+    const int b = width(np);
+    if (np < 1 || b < 2 || b > 32 || k::jmc_lds_bytes(nc, b, sizeof(T)) > (size_t)160 * 1024) return false;
+    *nc_out = nc;
+    *np_out = np;
+    *b_out = b;
+    return true;
+  }
+  template <class T, int NC>
+  void jmc_launch_step(int np, int b, T* w, T* v, int nblocks, int step, int sweep, T tol, T tol_early, k::JmcCtl* ctl) {
+    const size_t lds = k::jmc_lds_bytes(NC, b, sizeof(T));
+    const unsigned threads = (unsigned)((b * k::kJmcLanes + 63) / 64 * 64);
+    hipLaunchKernelGGL((k::jmc_step_kernel<T, NC>), dim3((unsigned)np), dim3(threads), lds, stream, w, v, b, nblocks, step,
+                       sweep, step == 0 ? 1 : 0, tol, tol_early, ctl);
+  }
+  // conv_status: device CholStatus record that receives the convergence verdict of the fixed number of sweeps
+  // enqueued without any synchronisation (the caller checks it later); nullptr: sweeps are enqueued in groups and the
+  // host waits for each group until the iteration has converged
+  template <class T>
+  void small_svd_mc(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev, void* conv_status) {
+    int nc = 0, np = 0, b = 0;
+    if (!jmc_geometry<T>(l, &nc, &np, &b)) throw Error(ST_EINVAL, "internal: core too large for the multi-workgroup Jacobi");
+    // global column pitch = LDS column pitch: a block of b columns is one contiguous byte range in both
+    const int rp = k::jmc_pitch(nc, (int)sizeof(T)), nblocks = 2 * np, ncols_pad = nblocks * b;
+    T* wj = (T*)alloc_bytes((size_t)rp * ncols_pad * sizeof(T));
+    T* vj = (T*)alloc_bytes((size_t)rp * ncols_pad * sizeof(T));
+    k::JmcCtl* ctl = (k::JmcCtl*)alloc_bytes(sizeof(k::JmcCtl));
+    k::CholStatus* st = conv_status ? (k::CholStatus*)conv_status : (k::CholStatus*)alloc_bytes(sizeof(k::CholStatus));
+    // optimistic calls (conv_status given) may use the W-only mode when the core is well conditioned; the
+    // host-controlled repeat always accumulates V
+    const int force_v = (conv_status == nullptr || env_int("CORRLA_JMC_FORCE_V", 0)) ? 1 : 0;
+    hipLaunchKernelGGL((k::jmc_init_kernel<T>), dim3(1), dim3(1024), 0, stream, (const T*)c.p, c.ld, (int)l, wj, vj, rp,
+                       ncols_pad, force_v, ctl);
+    const double eps = (double)std::numeric_limits<T>::epsilon();
+    const T tol = (T)(std::sqrt((double)l) * eps);
+    // strict termination: the iteration ends with a sweep that rotated nothing.  (Ending one sweep earlier, when no
+    // pair exceeded sqrt(eps), relies on quadratic convergence, which clustered singular values do not give: the
+    // W / sigma factor of a 1.25e6 x 512 Gaussian sketch came out orthonormal to 6e-5 only.)
+    const T tol_early = tol;
+    auto enqueue_sweeps = [&](int s0, int s1) {
+      for (int sw = s0; sw < s1; ++sw)
+        for (int step = 0; step < nblocks - 1; ++step) switch (nc) {
+            case 1: jmc_launch_step<T, 1>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 2: jmc_launch_step<T, 2>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 3: jmc_launch_step<T, 3>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 4: jmc_launch_step<T, 4>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 5: jmc_launch_step<T, 5>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 6: jmc_launch_step<T, 6>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 7: jmc_launch_step<T, 7>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 8: jmc_launch_step<T, 8>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            default: jmc_launch_step<T, 9>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+          }
+      CORRLA_HIP(hipGetLastError());
+    };
+    const size_t lds_fin = (size_t)(l + 2) * sizeof(T) + (size_t)(l + 2) * sizeof(int) + 64;
+    auto finish = [&](int nsw) {
+      hipLaunchKernelGGL((k::jmc_finish_kernel<T>), dim3(1), dim3(1024), lds_fin, stream, (const T*)wj, (const T*)vj, rp, (int)l,
+                         nsw, (const k::JmcCtl*)ctl, m1.p, m1.ld, m2.p, m2.ld, s_dev, (int)k, st);
+      // W-only mode: the accumulated-rotation factor is recovered from the core itself (no-op otherwise)
+      const unsigned groups = (unsigned)(l * k);
+      hipLaunchKernelGGL((k::jmc_other_factor_kernel<T>), dim3((groups * 16 + 255) / 256), dim3(256), 0, stream, (const T*)c.p,
+                         c.ld, (int)l, (int)k, (const T*)m2.p, m2.ld, (const T*)s_dev, (const k::JmcCtl*)ctl, m1.p, m1.ld);
+      CORRLA_HIP(hipGetLastError());
+    };
+    if (conv_status) {
+      const int nsw = std::min(k::kJmcMaxSweeps, std::max(1, env_int("CORRLA_JMC_SWEEPS", sizeof(T) == 4 ? 10 : 13)));
+      enqueue_sweeps(0, nsw);
+      finish(nsw);
+      if (env_int("CORRLA_DEBUG", 0)) {
+        k::JmcCtl hd;
+        CORRLA_HIP(hipMemcpyAsync(&hd, ctl, sizeof(hd), hipMemcpyDeviceToHost, stream));
+        sync();
+        int used = 0;
+        while (used < nsw && hd.rot[used] && hd.big[used]) ++used;
+        std::fprintf(stderr, "[corrla] jacobi_svd (multi-workgroup, %d sweeps enqueued, %s) l=%d np=%d b=%d nc=%d sweeps run=%d rounds(wg0)=%llu "
+                             "cycles/round=%.0f ns/round=%.0f (%.0f MHz)\n", nsw, hd.with_v ? "V accumulated" : "W only", (int)l, np, b, nc, std::min(used + 1, nsw),
+                     hd.rounds, hd.rounds ? (double)hd.clk / hd.rounds : 0.0, hd.rounds ? 10.0 * hd.wall / hd.rounds : 0.0,
+                     hd.wall ? 100.0 * hd.clk / hd.wall : 0.0);
+        if (hd.steps)
+          std::fprintf(stderr, "[corrla]   per step (wg0, us): load %.2f norms %.2f rounds %.2f store %.2f total %.2f over %llu steps\n",
+                       0.01 * hd.t_load / hd.steps, 0.01 * hd.t_norm / hd.steps, 0.01 * hd.wall / hd.steps,
+                       0.01 * hd.t_store / hd.steps, 0.01 * hd.t_total / hd.steps, hd.steps);
+        if (hd.steps > 1)
+          std::fprintf(stderr, "[corrla]   span first-start..last-end over all workgroups: %.2f us per step\n",
+                       0.01 * hd.t_span / (hd.steps - 1));
+      }
+      return;
+    }
+    int done = 0;
+    k::JmcCtl h;
+    while (done < k::kJmcMaxSweeps) {
+      const int s1 = std::min(k::kJmcMaxSweeps, done + 8);
+      enqueue_sweeps(done, s1);
+      CORRLA_HIP(hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
+      sync();
+      bool conv = false;
+      for (int s_ = 0; s_ < s1; ++s_) conv = conv || !(h.rot[s_] && h.big[s_]);
+      done = s1;
+      if (conv || h.bad) break;
+    }
+    finish(done);
+    if (env_int("CORRLA_DEBUG", 0)) {
+      int used = 0;
+      while (used < done && h.rot[used] && h.big[used]) ++used;
+      std::fprintf(stderr, "[corrla] jacobi_svd (multi-workgroup) l=%d np=%d b=%d sweeps=%d\n", (int)l, np, b, used + 1);
+    }
+  }
+
   template <class T, int BIG_E>
   void set_ring_attrs() {
     const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
@@ -519,8 +682,20 @@ class HipDev {
   // in LDS, block Jacobi over many waves otherwise (any l up to 1024).  CORRLA_SVD=block / host force the
   // block kernel / the f64 host Jacobi.
   template <class T>
-  void small_svd(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev) {
+  void small_svd(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev, void* conv_status) {
+    // conv_status (optional): a device status record; kernels that run a FIXED number of sweeps report there
+    // whether they converged, the others (loop to convergence inside one launch) leave it cleared = converged
+    if (conv_status) memset_zero(conv_status, sizeof(k::CholStatus));
     const char* mode = std::getenv("CORRLA_SVD");
+    {
+      int nc_, np_, b_;
+      const bool want_mc = mode && std::strcmp(mode, "mc") == 0;
+      const bool want_other = mode && !want_mc;
+      if (!want_other && !env_int("CORRLA_HOST_SVD", 0) && (want_mc || l >= jmc_min_l_) && jmc_geometry<T>(l, &nc_, &np_, &b_)) {
+        small_svd_mc(c, l, k, m1, m2, s_dev, conv_status);
+        return;
+      }
+    }
     const bool want_host = (mode && std::strcmp(mode, "host") == 0) || env_int("CORRLA_HOST_SVD", 0);
     const bool want_lds = mode && std::strcmp(mode, "lds") == 0;
     if (want_host || l > 1024) {
@@ -586,7 +761,8 @@ class HipDev {
     int* info = (int*)alloc_bytes(sizeof(int) * 4);
     const double eps = (double)std::numeric_limits<T>::epsilon();
     const T tol = (T)(std::sqrt((double)l) * eps);
-    const T tol_early = (T)std::sqrt(eps);  // quadratic convergence: a sweep that starts below this ends below tol
+    // strict termination (see small_svd_mc): quadratic convergence cannot be relied on for clustered singular values
+    const T tol_early = env_int("CORRLA_JACOBI_EARLY", 0) ? (T)std::sqrt(eps) : tol;
     const bool v_lds = lds2 <= kLdsMax;
     const size_t lds = v_lds ? lds2 : lds1;
     // ring kernel: columns resident in registers (l <= 144)
@@ -892,6 +1068,7 @@ class HipDev {
   int split_nn_override_ = 0, split_tn_override_ = 0, mw_override_ = 0, gemm_debug_flags_ = 0;
   uint64_t entropy_ = 0, calls_ = 0, calls_sharded_ = 0;
   bool no_device_chol_ = false;
+  int jmc_min_l_ = 145, jmc_max_b_ = 24;
 
   static void check_grid(const dim3& g) {
     if (g.y > 65535u || g.z > 65535u) throw Error(ST_EINVAL, "problem too large for the launch grid");
@@ -904,6 +1081,8 @@ class HipDev {
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_tn_kernel<T, 1, NT>, attr, k::gemm_lds_bytes(1, NT)));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_nn_kernel<T, 2, NT>, attr, k::gemm_lds_bytes(2, NT)));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_tn_kernel<T, 2, NT>, attr, k::gemm_lds_bytes(2, NT)));
+    if constexpr (NT <= 8)
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_nn_kernel<T, 2, NT, true>, attr, 3 * k::big_tile_bytes(2)));
   }
   template <class T>
   static void set_jacobi_attrs() {
@@ -954,12 +1133,20 @@ class HipDev {
 
   template <class T, int MW, int NT>
   void launch_one(bool tn, dim3 grid, const k::GemmArgs<T>& a) {
-    const int lds = k::gemm_lds_bytes(MW, NT);
+    // the kernels only touch ring buffers [0, min(tiles per workgroup, stages)): a short reduction (the l-deep
+    // products Y * R^-1 and U = Q * U~ have 2-3 tiles) asks for less LDS, so several workgroups share a CU and one's
+    // load latency hides behind another's MFMAs and stores
+    const int lds = std::min(k::gemm_stages(MW, NT), std::max(1, a.tiles_per_split)) * k::stage_bytes(MW, NT);
     const dim3 block(64 * (4 + k::kLoaders));  // 4 MFMA waves + loader wave(s)
     if (tn)
       hipLaunchKernelGGL((k::gemm_tn_kernel<T, MW, NT>), grid, block, lds, stream, a);
     else
       hipLaunchKernelGGL((k::gemm_nn_kernel<T, MW, NT>), grid, block, lds, stream, a);
+  }
+  template <class T, int NT>
+  void launch_alias(dim3 grid, const k::GemmArgs<T>& a) {
+    const dim3 block(64 * (4 + k::kLoaders));
+    hipLaunchKernelGGL((k::gemm_nn_kernel<T, 2, NT, true>), grid, block, 3 * k::big_tile_bytes(2), stream, a);
   }
   template <class T, int NT>
   void launch_mw(bool tn, int mw, dim3 grid, const k::GemmArgs<T>& a) {
@@ -976,7 +1163,8 @@ class HipDev {
     constexpr int KT = k::MT<T>::KT;
     constexpr int VEC = k::MT<T>::VEC;
     const ColBlocking cb = col_blocking(x.cols);
-    if (cb.cols_alloc > x.cols_alloc || cb.cols_alloc > out.cols_alloc)
+    if (x.external) throw Error(ST_EINVAL, "internal: an external buffer cannot be a padded operand");
+    if (cb.cols_alloc > x.cols_alloc || (!out.external && cb.cols_alloc > out.cols_alloc) || (out.external && out.cols < x.cols))
       throw Error(ST_EINVAL, "internal: skinny column padding too small for the column blocking");
     if (out.rows != outer_n || out.ld < outer_n) throw Error(ST_EINVAL, "internal: gemm output shape mismatch");
     if (((uintptr_t)r.p % 16) || (r.ld % VEC) || (r.cols_readable % VEC) || ((uintptr_t)x.p % 16))
@@ -987,6 +1175,16 @@ class HipDev {
     if (x.ld < (int64_t)tiles_total * KT) throw Error(ST_EINVAL, "internal: skinny leading dimension too small");
     int mw = 1, nsplit = 1;
     choose_geometry(tn, outer_n, cb.nblk, tiles_total, &mw, &nsplit);
+    // Gram matrix G = Y^T Y: both operands are the same memory and one outer tile (MW = 2: 128 indices) holds every
+    // column -> the aliased instantiation stages Y once per tile
+    const bool alias = !tn && (const void*)r.p == (const void*)x.p && r.ld == x.ld && cb.nblk == 1 && outer_n <= 128 &&
+                       cb.nt <= 8 && outer_n == x.cols && !env_int("CORRLA_NO_GRAM_ALIAS", 0);
+    if (alias) {
+      mw = 2;
+      const int64_t wgs1 = 1;
+      nsplit = (int)std::min<int64_t>(std::max<int64_t>(1, tiles_total / 4), 2 * (int64_t)num_cus / wgs1);
+      if (split_nn_override_ > 0) nsplit = std::min(split_nn_override_, tiles_total);
+    }
     const int64_t outer_tiles = (outer_n + 64 * mw - 1) / (64 * mw);
     if (outer_tiles > 0x7fffffff) throw Error(ST_EINVAL, "outer dimension too large");
     k::GemmArgs<T> a;
@@ -999,6 +1197,7 @@ class HipDev {
     a.x_ld = x.ld;
     a.out = out.p;
     a.out_ld = out.ld;
+    a.out_cols = out.external ? out.cols : cb.cols_alloc;
     a.scale = scale_dev;
     a.zero = (const T*)zero_page_;
     a.tiles_total = tiles_total;
@@ -1010,6 +1209,18 @@ class HipDev {
     if (nsplit > 1) a.slab = (T*)alloc_bytes((size_t)nsplit * (size_t)a.slab_stride * sizeof(T));
     dim3 grid((unsigned)outer_tiles, (unsigned)cb.nblk, (unsigned)nsplit);
     check_grid(grid);
+    if (alias) {
+      switch (cb.nt) {
+        case 1: launch_alias<T, 1>(grid, a); break;
+        case 2: launch_alias<T, 2>(grid, a); break;
+        case 3: launch_alias<T, 3>(grid, a); break;
+        case 4: launch_alias<T, 4>(grid, a); break;
+        case 5: launch_alias<T, 5>(grid, a); break;
+        case 6: launch_alias<T, 6>(grid, a); break;
+        case 7: launch_alias<T, 7>(grid, a); break;
+        default: launch_alias<T, 8>(grid, a); break;
+      }
+    } else
     switch (cb.nt) {
       case 1: launch_mw<T, 1>(tn, mw, grid, a); break;
       case 2: launch_mw<T, 2>(tn, mw, grid, a); break;
@@ -1027,13 +1238,13 @@ class HipDev {
       dim3 rg((unsigned)((outer_n + 63) / 64), (unsigned)cb.cols_alloc);
       check_grid(rg);
       hipLaunchKernelGGL((k::slab_reduce_deep_kernel<T>), rg, dim3(256), 0, stream, (const T*)a.slab, a.slab_stride,
-                         nsplit, out.p, out.ld, outer_n, cb.cols_alloc, scale_dev);
+                         nsplit, out.p, out.ld, outer_n, a.out_cols, scale_dev);
       CORRLA_HIP(hipGetLastError());
     } else if (nsplit > 1) {
       dim3 rg((unsigned)((outer_n + 255) / 256), (unsigned)cb.cols_alloc);
       check_grid(rg);
       hipLaunchKernelGGL((k::slab_reduce_kernel<T>), rg, dim3(256), 0, stream, (const T*)a.slab, a.slab_stride, nsplit,
-                         out.p, out.ld, outer_n, cb.cols_alloc, scale_dev);
+                         out.p, out.ld, outer_n, a.out_cols, scale_dev);
       CORRLA_HIP(hipGetLastError());
     }
   }

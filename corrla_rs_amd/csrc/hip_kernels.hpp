@@ -110,6 +110,7 @@ struct GemmArgs {
   int64_t x_ld;
   T* out;             // skinny result, column-major
   int64_t out_ld;
+  int64_t out_cols;   // columns of `out` that may be written (the padded column count, or fewer for a caller's buffer)
   T* slab;            // partial results when nsplit > 1: slab[z][col][outer]
   int64_t slab_stride;
   const T* scale;     // optional device scalar applied to the result (nsplit == 1 only)
@@ -209,7 +210,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t col = col0 + 16 * t + MT<T>::drow(lane, j);
-      dst[col * g.out_ld + outer] = acc[t][j] * sc;
+      if (g.nsplit > 1 || col < g.out_cols) dst[col * g.out_ld + outer] = acc[t][j] * sc;
     }
   }
 }
@@ -217,14 +218,18 @@ __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename 
 // ---------------------------------------------------------------------------------------------
 // gemm_nn: grid = (ceil(R_rows/64), column blocks, nsplit)
 // ---------------------------------------------------------------------------------------------
-template <class T, int MW, int NT>
+// ALIAS (Gram matrices, G = Y^T Y: the big operand's memory IS the skinny operand's, and the single outer tile
+// holds every column): the skinny fragments are read from the big tile's LDS image -- same rows, same swizzle -- so
+// the operand is staged ONCE per tile instead of twice (the Gram of a 10^7 x 80 sketch read Y twice: 6.4 GB).
+template <class T, int MW, int NT, bool ALIAS = false>
 __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T> g) {
   typedef typename MT<T>::acc_t acc_t;
   typedef typename MT<T>::vec_t vec_t;
   constexpr int VEC = MT<T>::VEC;
   constexpr int KT = MT<T>::KT;
-  constexpr int STAGE = stage_bytes(MW, NT);
+  constexpr int STAGE = ALIAS ? big_tile_bytes(MW) : stage_bytes(MW, NT);
   constexpr int BIG = big_tile_bytes(MW);
+  static_assert(!ALIAS || 16 * NT <= 64 * MW, "alias: the outer tile must hold every column");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
     auto stage_checked = [&](int buf, int kt) {
       char* rt = smem + buf * STAGE;
       const int64_t k0 = (int64_t)kt * KT;
-      for (int c = wave - 4; c < 16 * MW; c += kLoaders) {
+      for (int c = wave - 4; c < (ALIAS ? 4 * NT : 16 * MW); c += kLoaders) {
         const int row = 4 * c + (lane >> 4);
         const int ls = (lane & 15) ^ (row & 15);
         const int64_t grow = row0 + row;
@@ -259,17 +264,20 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
         const T* src = (grow < g.r_rows && kk < g.r_cols_readable) ? g.r + grow * g.r_ld + kk : g.zero;
         glds16(src, rt + c * 1024);
       }
-      for (int c = wave - 4; c < 4 * NT; c += kLoaders) {
-        const int row = 4 * c + (lane >> 4);
-        const int ls = (lane & 15) ^ (row & 15);
-        glds16(g.x + (col0 + row) * g.x_ld + k0 + ls * VEC, rt + BIG + c * 1024);
-      }
+      if constexpr (!ALIAS)
+        for (int c = wave - 4; c < 4 * NT; c += kLoaders) {
+          const int row = 4 * c + (lane >> 4);
+          const int ls = (lane & 15) ^ (row & 15);
+          glds16(g.x + (col0 + row) * g.x_ld + k0 + ls * VEC, rt + BIG + c * 1024);
+        }
     };
     // pattern streams: chunk c covers tile rows 4c..4c+3 and (row & 15) repeats every 4 chunks; loader lw
     // of NL owns chunks c = lw + NL*i, i.e. NV = 4/NL pattern variants, each repeating every 16 rows
     constexpr int NL = kLoaders, NV = 4 / NL;
     const int lw = wave - 4;
-    DmaStream<NV, 4 * MW, NL> big;
+    // alias: only the 16 * NT rows that exist as (zero padded) columns of the sketch are staged; the rows above them
+    // feed accumulators whose outer index is >= r_rows and is never stored
+    DmaStream<NV, ALIAS ? NT : 4 * MW, NL> big;
     DmaStream<NV, NT, NL> sk;
 #pragma unroll
     for (int pv = 0; pv < NV; ++pv) {
@@ -282,12 +290,13 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
     big.adv = KT * (int64_t)sizeof(T);
     sk.step = 16 * g.x_ld * (int64_t)sizeof(T);
     sk.adv = KT * (int64_t)sizeof(T);
-    const bool rows_inside = row0 + outer_tile(MW) <= g.r_rows;
+    // alias: the host guarantees 16 * NT allocated columns (x.cols_alloc), all of them readable
+    const bool rows_inside = ALIAS ? true : (row0 + outer_tile(MW) <= g.r_rows);
     auto stage_tile = [&](int buf, int kt) {
       char* rt = smem + buf * STAGE;
       if (rows_inside && (int64_t)(kt + 1) * KT <= g.r_cols_readable) {
         big.issue(rt + lw * 1024);
-        sk.issue(rt + BIG + lw * 1024);
+        if constexpr (!ALIAS) sk.issue(rt + BIG + lw * 1024);
       } else {
         stage_checked(buf, kt);
 #pragma unroll
@@ -298,9 +307,9 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
       }
     };
     // ring of NSTAGE buffers: tiles i+1 .. i+NSTAGE-1 are in flight while the MFMA waves work on tile i
-    constexpr int NSTAGE = gemm_stages(MW, NT);
+    constexpr int NSTAGE = ALIAS ? 3 : gemm_stages(MW, NT);
     static_assert((16 * MW) % kLoaders == 0 && (4 * NT) % kLoaders == 0, "chunks must split evenly over the loaders");
-    constexpr int DPL = (16 * MW + 4 * NT) / kLoaders;  // DMA instructions per loader wave per tile
+    constexpr int DPL = ALIAS ? NT : (16 * MW + 4 * NT) / kLoaders;  // DMA instructions per loader wave per tile
     for (int t = 0; t < NSTAGE - 1 && t < nk; ++t) stage_tile(t % NSTAGE, t_begin + t);
     for (int i = 0; i < nk; ++i) {
       // tile i must have landed; the (NSTAGE-2) younger tiles may stay in flight (vmcnt counts in issue order)
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
     const unsigned so = (unsigned)(((4 * gq + fkq) ^ fc) << 4);
-    a_off[gq] = lds0 + BIG + fc * kRowBytes + so;
+    a_off[gq] = lds0 + (ALIAS ? 0 : BIG) + fc * kRowBytes + so;  // alias: column c of the sketch = row c of the big tile
     b_off[gq] = lds0 + (16 * MW * wave + fc) * kRowBytes + so;
   }
 
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
 
   for (int i = 0; i < nk; ++i) {
     wg_barrier();  // matches the loaders' barrier: tile i is in LDS (all of this wave's LDS reads are retired)
-    compute(i % gemm_stages(MW, NT), i > 0);
+    compute(i % (ALIAS ? 3 : gemm_stages(MW, NT)), i > 0);
   }
   if constexpr (kDefer > 0) {
     if (nk > 0) static_for<NS - kDefer, NS>(mfma_step);
@@ -794,6 +803,9 @@ __device__ __forceinline__ bool jacobi_rotation(float a, float b, float g, float
   t = copysignf(__builtin_amdgcn_rcpf(den), zeta);
   cs = __builtin_amdgcn_rsqf(1.f + t * t);
   sn = cs * t;
+  // two columns of subnormal size (exact-arithmetic null directions of an integer-valued core): rcp(g) overflows
+  // and (b - a) * inf is NaN or inf.  Such a pair carries no information; leave it alone rather than poison W.
+  if (!(fabsf(sn) <= 1.f && cs <= 1.f)) return false;
   return true;
 }
 __device__ __forceinline__ bool jacobi_rotation(float a, float b, float g, float tol, float& cs, float& sn, float& rel) {

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <vector>
 
@@ -91,6 +92,14 @@ class EmuDev {
     std::memset(s.p, 0, bytes);
     return s;
   }
+  template <class T>
+  Skinny<T> alloc_skinny_out(int64_t rows, int64_t cols) {
+    Skinny<T> s = alloc_skinny<T>(rows, cols);
+    // poison everything a product must overwrite, so that a consumer of stale "zeros" shows up in the CPU tests
+    for (int64_t c = 0; c < s.cols_alloc; ++c)
+      for (int64_t r = 0; r < rows; ++r) s.p[c * s.ld + r] = std::numeric_limits<T>::quiet_NaN();
+    return s;
+  }
   double* alloc_f64(int n) {
     double* p = (double*)alloc_bytes(sizeof(double) * n);
     std::memset(p, 0, sizeof(double) * n);
@@ -111,10 +120,10 @@ class EmuDev {
   void gemm_nn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale) {
     if (x.rows != r.cols) throw Error(ST_EINVAL, "gemm_nn: inner dimensions differ");
     const ColBlocking cb = col_blocking(x.cols);
-    if (cb.cols_alloc > x.cols_alloc || cb.cols_alloc > out.cols_alloc) throw Error(ST_EINVAL, "emu: column padding");
+    if (cb.cols_alloc > x.cols_alloc || (!out.external && cb.cols_alloc > out.cols_alloc)) throw Error(ST_EINVAL, "emu: column padding");
     if (out.rows != r.rows) throw Error(ST_EINVAL, "emu: gemm output shape mismatch");
     const double sc = scale ? (double)*scale : 1.0;
-    for (int64_t c = 0; c < cb.cols_alloc; ++c)
+    for (int64_t c = 0; c < (out.external ? out.cols : cb.cols_alloc); ++c)
       for (int64_t i = 0; i < r.rows; ++i) {
         double s = 0.0;
         for (int64_t kk = 0; kk < r.cols; ++kk) s += (double)r.p[i * r.ld + kk] * (double)x.p[c * x.ld + kk];
@@ -125,10 +134,10 @@ class EmuDev {
   void gemm_tn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale) {
     if (x.rows != r.rows) throw Error(ST_EINVAL, "gemm_tn: inner dimensions differ");
     const ColBlocking cb = col_blocking(x.cols);
-    if (cb.cols_alloc > x.cols_alloc || cb.cols_alloc > out.cols_alloc) throw Error(ST_EINVAL, "emu: column padding");
+    if (cb.cols_alloc > x.cols_alloc || (!out.external && cb.cols_alloc > out.cols_alloc)) throw Error(ST_EINVAL, "emu: column padding");
     if (out.rows != r.cols) throw Error(ST_EINVAL, "emu: gemm output shape mismatch");
     const double sc = scale ? (double)*scale : 1.0;
-    for (int64_t c = 0; c < cb.cols_alloc; ++c)
+    for (int64_t c = 0; c < (out.external ? out.cols : cb.cols_alloc); ++c)
       for (int64_t j = 0; j < r.cols; ++j) {
         double s = 0.0;
         for (int64_t i = 0; i < r.rows; ++i) s += (double)r.p[i * r.ld + j] * (double)x.p[c * x.ld + i];
@@ -412,7 +421,8 @@ class EmuDev {
   template <class T>
   void copy_values_out(const T* src, int64_t n, T* dst, bool) { std::memcpy(dst, src, sizeof(T) * n); }
   template <class T>
-  void small_svd(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev) {
+  void small_svd(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev, void* conv_status) {
+    if (conv_status) std::memset(conv_status, 0, sizeof(EmuCholStatus));
     small_svd_host(*this, c, l, k, m1, m2, s_dev);
   }
   template <class T>

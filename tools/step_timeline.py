@@ -39,9 +39,19 @@ def main():
         print("not enough rsvd calls in the trace")
         return
     def call_end(i):
-        j = i
-        while j + 1 < len(rows) and ("copy_out" in rows[j + 1][0] or "apply_column_sign" in rows[j + 1][0]):
-            j += 1
+        # after the sign kernel: sign application, ONE tall product (U = Q U~, written in place), output copies
+        j, gemms = i, 0
+        while j + 1 < len(rows):
+            n = rows[j + 1][0]
+            if "copy_out" in n or "apply_column_sign" in n or "copyBuffer" in n:
+                j += 1
+            elif "gemm_tn_kernel" in n and gemms == 0:
+                gemms += 1
+                j += 1
+            elif "slab_reduce" in n and gemms == 1:
+                j += 1
+            else:
+                break
         return j
     first = call_end(signs[call - 2]) + 1
     last = call_end(signs[call - 1])
