@@ -596,6 +596,16 @@ struct RsvdDriver {
       st_used_ += 1;
     }
     dev.small_svd(ct, l, k, m2, m1, s_dev, svd_st);
+    int64_t nz_known = k;
+    if (defer_status_) {
+      // One-sided Jacobi leaves the W / sigma factor (here m1 = U~) orthonormal only to the size of the last
+      // rotations it skipped, which for clustered singular values is far above eps (6e-5 in f32 for the top 74 values
+      // of a 1.25e6 x 512 Gaussian matrix).  One Cholesky-QR pass restores it to working precision: R is I + O(1e-4), so the
+      // triplets move by less than their own uncertainty.  (The accumulated-rotation factor m2 is orthogonal by
+      // construction.)  A rank-deficient core fails the pass and the call repeats on the host-controlled path.
+      Skinny<T> m1b = dev.template alloc_skinny<T>(l, k);
+      orthonormalize_core(m1, m1b, false, /*rough=*/true);
+    }
     if (!defer_status_) {
       // Exactly singular core (rank-deficient or zero input; only reachable through the host-controlled path): the
       // vectors w_j / sigma_j of its null triplets (here: columns of Vc, the Jacobi runs on C^T) do not exist.  Give
@@ -608,7 +618,13 @@ struct RsvdDriver {
       int64_t nz = 0;
       while (nz < k && sh[(size_t)nz] > null_tol) ++nz;
       if (nz < k) complete_basis(m1, nz, false);
+      nz_known = nz;
+      if (nz == k) {
+        Skinny<T> m1b = dev.template alloc_skinny<T>(l, k);
+        orthonormalize_core(m1, m1b, false, /*rough=*/true);
+      }
     }
+    (void)nz_known;
     phase(tm.small_svd_ms, pt);
     // V = Qb * Uc[:, :k]
     dev.gemm_tn(as_rowmajor_transposed(qb, l), m2, v_tall, kNone);

@@ -103,7 +103,7 @@ class HipDev {
     split_tn_override_ = env_int("CORRLA_SPLIT_TN", 0);
     mw_override_ = env_int("CORRLA_MW", 0);
     no_device_chol_ = env_int("CORRLA_HOST_CHOL", 0) != 0;
-    jmc_min_l_ = env_int("CORRLA_JMC_MIN_L", 145);  // l <= 144: the register-resident ring kernel + replay is as fast
+    jmc_min_l_ = env_int("CORRLA_JMC_MIN_L", 96);  // below: the single-workgroup ring kernel + replay is as fast (one launch)
     jmc_max_b_ = std::min(32, std::max(2, env_int("CORRLA_JMC_MAX_B", 24)));
     gemm_debug_flags_ = env_int("CORRLA_GEMM_DEBUG", 0);  // timing-only ablations, results are wrong
   }
@@ -589,10 +589,11 @@ class HipDev {
                        ncols_pad, force_v, ctl);
     const double eps = (double)std::numeric_limits<T>::epsilon();
     const T tol = (T)(std::sqrt((double)l) * eps);
-    // strict termination: the iteration ends with a sweep that rotated nothing.  (Ending one sweep earlier, when no
-    // pair exceeded sqrt(eps), relies on quadratic convergence, which clustered singular values do not give: the
-    // W / sigma factor of a 1.25e6 x 512 Gaussian sketch came out orthonormal to 6e-5 only.)
-    const T tol_early = tol;
+    // The iteration ends with the sweep in which no pair exceeded sqrt(eps) (quadratic convergence).  Clustered
+    // singular values do not converge quadratically: the W / sigma factor of a 1.25e6 x 512 Gaussian sketch came out
+    // orthonormal to 6e-5 only.  Running to a sweep without any rotation costs two more sweeps; the driver instead
+    // re-orthonormalises that factor with one Cholesky-QR pass (a first-order (I + E)^-1/2 here), which is cheaper.
+    const T tol_early = env_int("CORRLA_JACOBI_STRICT", 0) ? tol : (T)std::sqrt(eps);
     auto enqueue_sweeps = [&](int s0, int s1) {
       for (int sw = s0; sw < s1; ++sw)
         for (int step = 0; step < nblocks - 1; ++step) switch (nc) {
@@ -761,8 +762,9 @@ class HipDev {
     int* info = (int*)alloc_bytes(sizeof(int) * 4);
     const double eps = (double)std::numeric_limits<T>::epsilon();
     const T tol = (T)(std::sqrt((double)l) * eps);
-    // strict termination (see small_svd_mc): quadratic convergence cannot be relied on for clustered singular values
-    const T tol_early = env_int("CORRLA_JACOBI_EARLY", 0) ? (T)std::sqrt(eps) : tol;
+    // quadratic convergence: a sweep that starts below sqrt(eps) ends below tol -- except for clustered singular
+    // values, whose W / sigma factor the driver re-orthonormalises afterwards (see small_svd_mc)
+    const T tol_early = env_int("CORRLA_JACOBI_STRICT", 0) ? tol : (T)std::sqrt(eps);
     const bool v_lds = lds2 <= kLdsMax;
     const size_t lds = v_lds ? lds2 : lds1;
     // ring kernel: columns resident in registers (l <= 144)
@@ -1068,7 +1070,7 @@ class HipDev {
   int split_nn_override_ = 0, split_tn_override_ = 0, mw_override_ = 0, gemm_debug_flags_ = 0;
   uint64_t entropy_ = 0, calls_ = 0, calls_sharded_ = 0;
   bool no_device_chol_ = false;
-  int jmc_min_l_ = 145, jmc_max_b_ = 24;
+  int jmc_min_l_ = 96, jmc_max_b_ = 24;
 
   static void check_grid(const dim3& g) {
     if (g.y > 65535u || g.z > 65535u) throw Error(ST_EINVAL, "problem too large for the launch grid");
