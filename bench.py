@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", action="store_true",
+                    help="CORRLA_POWER_FUSED: one-sweep A^T (A Z) power iteration (SURVEY 8 f4; n <= 512 f32, i.e. --config C4)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -233,8 +235,8 @@ def main():
 
     def step():
         if use_dist:
-            return ctx.rsvd_sharded(a, k, q, p, seed=SEED_OMEGA)
-        return ctx.rsvd(a, k, q, p, seed=SEED_OMEGA)
+            return ctx.rsvd_sharded(a, k, q, p, seed=SEED_OMEGA, fused=args.fused)
+        return ctx.rsvd(a, k, q, p, seed=SEED_OMEGA, fused=args.fused)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -319,6 +321,7 @@ def main():
                        "pct_of_f32_mfma_peak_whole_job": round(100 * value / 1e3 / (PEAK_F32_MFMA_TFLOPS * world), 2)},
             "roofline": roofline,
             "phases_ms_last_step": phases,
+            "schedule": "one-sweep A^T (A Z) (CORRLA_POWER_FUSED)" if args.fused else "reference (two products per iteration)",
             "collectives": {"rccl_nranks": nranks_seen, "allreduces_per_step": tm["n_collectives"],
                             "allreduce_bytes_per_step": tm["collective_bytes"]},
         }

@@ -15,6 +15,7 @@ PCA_CENTER_FUSED = 0x2
 PCA_CENTER_COPY = 0x4
 QR_HOUSEHOLDER = 0x8
 SEED_EXPLICIT = 0x10
+POWER_FUSED = 0x20
 UNIQUE_ID_BYTES = 128
 
 

@@ -131,10 +131,11 @@ class Context:
         return o, keep
 
     # ---- random_svd ----------------------------------------------------------------------
-    def rsvd(self, a_mat, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, qr=None):
+    def rsvd(self, a_mat, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, qr=None, fused=False):
+        """fused=True: CORRLA_POWER_FUSED (one-sweep A^T (A Z) power iteration; f32 row-major inputs with <= 512 columns)."""
         n_rank, n_iters, n_oversamples = int(n_rank), int(n_iters), int(n_oversamples)
         if _is_torch(a_mat) and a_mat.is_cuda:
-            return self._rsvd_torch(a_mat, n_rank, n_iters, n_oversamples, seed, omega, qr=qr)
+            return self._rsvd_torch(a_mat, n_rank, n_iters, n_oversamples, seed, omega, qr=qr, fused=fused)
         a = np.asarray(a_mat.detach().cpu().numpy() if _is_torch(a_mat) else a_mat)
         if a.ndim != 2:
             raise ValueError("a_mat must be 2-D")
@@ -150,7 +151,7 @@ class Context:
         k = n_rank
         nt = min(m, n)
         l = min(k + max(n_oversamples, 0), nt)
-        o, keep = self._opts(seed, omega, nt, l, a.dtype, False, self._qr_flag(qr))
+        o, keep = self._opts(seed, omega, nt, l, a.dtype, False, self._qr_flag(qr) | (L.POWER_FUSED if fused else 0))
         kk = max(k, 1)
         u = np.empty((m, kk), dtype=a.dtype, order="F")
         s = np.empty((kk, 1), dtype=a.dtype, order="F")
@@ -161,7 +162,7 @@ class Context:
         del keep
         return u, s, vt
 
-    def _rsvd_torch(self, a, k, q, p, seed, omega, sharded=False, qr=None):
+    def _rsvd_torch(self, a, k, q, p, seed, omega, sharded=False, qr=None, fused=False):
         import torch
         if a.dim() != 2:
             raise ValueError("a_mat must be 2-D")
@@ -178,7 +179,7 @@ class Context:
         suf = "f32" if a.dtype == torch.float32 else "f64"
         nt = n if sharded else min(m, n)
         l = min(k + max(p, 0), nt)
-        o, keep = self._opts(seed, omega, nt, l, a.dtype, True, self._qr_flag(qr))
+        o, keep = self._opts(seed, omega, nt, l, a.dtype, True, self._qr_flag(qr) | (L.POWER_FUSED if fused else 0))
         kk = max(k, 1)
         dev = a.device
         u = torch.empty((kk, m), dtype=a.dtype, device=dev).t()     # (m, k) column-major
@@ -192,10 +193,10 @@ class Context:
         del keep
         return u, s, vt
 
-    def rsvd_sharded(self, a_local, n_rank, n_iters, n_oversamples, *, seed=None, omega=None):
+    def rsvd_sharded(self, a_local, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, fused=False):
         """Row-sharded random_svd: `a_local` holds this rank's rows of the tall
         matrix as a torch CUDA tensor; returns (U_local, S, Vt) with S, Vt replicated."""
-        return self._rsvd_torch(a_local, int(n_rank), int(n_iters), int(n_oversamples), seed, omega, sharded=True)
+        return self._rsvd_torch(a_local, int(n_rank), int(n_iters), int(n_oversamples), seed, omega, sharded=True, fused=fused)
 
     # ---- PCA caller (pca_rsvd.rs:56-82) ---------------------------------------------------
     def pca(self, x_mat, rank, n_iter=None, n_oversamples=None, *, seed=None, omega=None, center=None):

@@ -38,6 +38,8 @@ inline RunOpts parse_opts(const corrla_opts* o, bool dev_ptrs) {
   RunOpts r;
   const char* qr_env = std::getenv("CORRLA_QR");
   r.qr_householder = qr_env && std::strcmp(qr_env, "householder") == 0;
+  const char* fu_env = std::getenv("CORRLA_POWER_FUSED");
+  r.power_fused = fu_env && std::atoi(fu_env) != 0;
   if (!o) return r;
   if (o->struct_size != sizeof(corrla_opts)) throw Error(ST_EINVAL, "corrla_opts.struct_size mismatch");
   // seed: used as given when it is non-zero or CORRLA_SEED_EXPLICIT is set (so 0 is a usable seed); otherwise every
@@ -52,6 +54,7 @@ inline RunOpts parse_opts(const corrla_opts* o, bool dev_ptrs) {
     throw Error(ST_EINVAL, "CORRLA_PCA_CENTER_FUSED and CORRLA_PCA_CENTER_COPY are mutually exclusive");
   r.pca_center = (o->flags & CORRLA_PCA_CENTER_FUSED) ? 1 : ((o->flags & CORRLA_PCA_CENTER_COPY) ? 2 : 0);
   r.qr_householder = r.qr_householder || (o->flags & CORRLA_QR_HOUSEHOLDER) != 0;
+  r.power_fused = r.power_fused || (o->flags & CORRLA_POWER_FUSED) != 0;
   return r;
 }
 

@@ -102,6 +102,7 @@ struct RunOpts {
   bool sharded = false;  // rows of A are sharded over the communicator
   int pca_center = 0;    // 0 default, 1 fused, 2 centred copy (corrla_pca_* only)
   bool qr_householder = false;  // thin-Q by Householder TSQR instead of CholeskyQR2 (CORRLA_QR_HOUSEHOLDER)
+  bool power_fused = false;     // one-sweep Z' = A^T (A Z) where it applies (CORRLA_POWER_FUSED)
 };
 
 struct Timings {
@@ -473,11 +474,34 @@ struct RsvdDriver {
     Skinny<T> z = dev.template alloc_skinny<T>(a.nt, l);
     double* ss_dev = dev.alloc_f64(1);
     T* inv_dev = dev.template alloc_scalar<T>(1);
-    dev.event_mark(0);
-    a_times(a, om, y, kNone);  // :31
-    dev.event_mark(1);
-    phase(tm.sketch_ms, pt);
-    for (int64_t i = 0; i < n_iter; ++i) {  // :35
+    // One-sweep schedule: Y = A X followed by Z = A^T Y is the single product Z = A^T (A X) whenever
+    // Y itself is not needed, i.e. for the sketch and the iterations without the in-loop thin-Q (i <= 2, :37-39):
+    //   Z(0) = A^T (A Omega), Z(i) = A^T (A Z^(i-1)), i < nf = min(q, 3);  then Y = A Z^(nf-1) and the loop continues
+    // with the reference's own steps.  A is read nf + 1 times instead of 2 nf + 1 and no m x l matrix is written.
+    int64_t i0 = 0;
+    const bool fused = o.power_fused && n_iter > 0 && a.row_major && !a.mu_short && !a.mu_tall &&
+                       dev.template ata_fused_fits<T>(a.mem, l);
+    if (fused) {
+      const int64_t nf = std::min<int64_t>(n_iter, 3);
+      for (int64_t i = 0; i < nf; ++i) {
+        if (i == 0) dev.event_mark(0);
+        dev.ata_fused(a.mem, i == 0 ? om : z, z);
+        if (i == 0) dev.event_mark(1);
+        if (o.sharded) dev.allreduce(z.p, (size_t)z.ld * (size_t)z.cols_alloc);
+        dev.sumsq(z, ss_dev);
+        dev.rsqrt_scalar(ss_dev, inv_dev);
+        dev.scale_inplace(z, inv_dev);
+        if (i == 0) phase(tm.sketch_ms, pt);
+      }
+      a_times(a, z, y, kNone);
+      i0 = nf;
+    } else {
+      dev.event_mark(0);
+      a_times(a, om, y, kNone);  // :31
+      dev.event_mark(1);
+      phase(tm.sketch_ms, pt);
+    }
+    for (int64_t i = i0; i < n_iter; ++i) {  // :35
       if (i > 2) {                          // :37-39
         phase(tm.power_ms, pt);
         orthonormalize(y, y2, o.sharded, /*rough=*/true);

@@ -19,6 +19,7 @@
 #include "hip_kernels.hpp"
 #include "tsqr_kernels.hpp"
 #include "jacobi_mc_kernels.hpp"
+#include "ata_kernels.hpp"
 
 namespace corrla {
 
@@ -87,6 +88,17 @@ class HipDev {
     set_tsqr_attrs<double>();
     set_jmc_attrs<float>();
     set_jmc_attrs<double>();
+    {
+      const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<1>, attr, k::ata_lds_bytes(1)));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<2>, attr, k::ata_lds_bytes(2)));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<3>, attr, k::ata_lds_bytes(3)));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<4>, attr, k::ata_lds_bytes(4)));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<5>, attr, k::ata_lds_bytes(5)));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<6>, attr, k::ata_lds_bytes(6)));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<7>, attr, k::ata_lds_bytes(7)));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<8>, attr, k::ata_lds_bytes(8)));
+    }
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<float>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<double>,
@@ -293,6 +305,66 @@ class HipDev {
     if (x.rows != r.rows) throw Error(ST_EINVAL, "gemm_tn: inner dimensions differ");
     launch_gemm<T>(true, r, x, out, scale_dev, r.cols, r.rows);
   }
+
+  // ---- one-sweep Z' = A^T (A Z) (ata_kernels.hpp): row-major f32 A with n <= 512 ----------------
+  template <class T>
+  bool ata_fused_fits(const Big<T>& a, int64_t l) const {
+    (void)l;
+    return std::is_same<T, float>::value && a.cols <= 512 && a.cols >= 16 && a.rows >= 64 * (int64_t)kAtaMinRowsPerGroup;
+  }
+  template <class T>
+  void ata_fused(const Big<T>& a, const Skinny<T>& x, Skinny<T>& z) {
+    if constexpr (!std::is_same<T, float>::value) {
+      throw Error(ST_EINVAL, "internal: the one-sweep power iteration is f32 only");
+    } else {
+      if (x.rows != a.cols || z.rows != a.cols) throw Error(ST_EINVAL, "ata_fused: shapes");
+      const ColBlocking cb = col_blocking(x.cols);
+      if (cb.cols_alloc > x.cols_alloc || cb.cols_alloc > z.cols_alloc || x.ld != z.ld)
+        throw Error(ST_EINVAL, "internal: ata_fused operands must share the padded layout");
+      if (((uintptr_t)a.p % 16) || (a.ld % 4) || (a.cols_readable % 4)) throw Error(ST_EINVAL, "internal: operand not vector aligned");
+      const int nk = (int)((a.cols + 63) / 64);
+      if (x.ld < 64 * nk) throw Error(ST_EINVAL, "internal: skinny leading dimension too small");
+      const int nct = (int)(cb.cols_alloc / 16);
+      // one workgroup per CU, row groups in multiples of 8 (the XCD count): ~all CUs busy in one wave of workgroups
+      int nrg = 8 * std::max(1, num_cus / (8 * nct));
+      const int64_t blocks = (a.rows + k::kAtaRows - 1) / k::kAtaRows;
+      if ((int64_t)nrg > blocks) nrg = (int)std::max<int64_t>(8, (blocks / 8) * 8);
+      const int64_t rows_per_group = ((blocks + nrg - 1) / nrg) * k::kAtaRows;
+      k::AtaArgs g;
+      g.a = a.p;
+      g.m = a.rows;
+      g.n = a.cols;
+      g.lda = a.ld;
+      g.n_readable = a.cols_readable;
+      g.z = x.p;
+      g.z_ld = x.ld;
+      g.out_ld = z.ld;
+      g.slab_stride = (int64_t)z.ld * cb.cols_alloc;
+      g.slab = (float*)alloc_zeroed((size_t)nrg * (size_t)g.slab_stride * sizeof(float));
+      g.rows_per_group = rows_per_group;
+      g.nrowgroups = nrg;
+      g.nct = nct;
+      g.zero = (const float*)zero_page_;
+      const dim3 grid((unsigned)(nrg * nct)), block(512);
+      switch (nk) {
+        case 1: hipLaunchKernelGGL((k::ata_fused_kernel<1>), grid, block, k::ata_lds_bytes(1), stream, g); break;
+        case 2: hipLaunchKernelGGL((k::ata_fused_kernel<2>), grid, block, k::ata_lds_bytes(2), stream, g); break;
+        case 3: hipLaunchKernelGGL((k::ata_fused_kernel<3>), grid, block, k::ata_lds_bytes(3), stream, g); break;
+        case 4: hipLaunchKernelGGL((k::ata_fused_kernel<4>), grid, block, k::ata_lds_bytes(4), stream, g); break;
+        case 5: hipLaunchKernelGGL((k::ata_fused_kernel<5>), grid, block, k::ata_lds_bytes(5), stream, g); break;
+        case 6: hipLaunchKernelGGL((k::ata_fused_kernel<6>), grid, block, k::ata_lds_bytes(6), stream, g); break;
+        case 7: hipLaunchKernelGGL((k::ata_fused_kernel<7>), grid, block, k::ata_lds_bytes(7), stream, g); break;
+        default: hipLaunchKernelGGL((k::ata_fused_kernel<8>), grid, block, k::ata_lds_bytes(8), stream, g); break;
+      }
+      CORRLA_HIP(hipGetLastError());
+      dim3 rgd((unsigned)((a.cols + 63) / 64), (unsigned)cb.cols_alloc);
+      check_grid(rgd);
+      hipLaunchKernelGGL((k::slab_reduce_deep_kernel<float>), rgd, dim3(256), 0, stream, (const float*)g.slab, g.slab_stride, nrg,
+                         z.p, z.ld, a.cols, cb.cols_alloc, (const float*)nullptr);
+      CORRLA_HIP(hipGetLastError());
+    }
+  }
+  static constexpr int kAtaMinRowsPerGroup = 64;
 
   // ---- collectives (RCCL over xGMI, on the compute stream) ---------------------------------
   template <class T>

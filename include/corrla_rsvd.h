@@ -74,6 +74,12 @@ typedef enum corrla_status {
  * (mat_utils.rs:161-175); on the row-sharded entry points that fresh seed is a function of the number of seedless
  * sharded calls made on the context only, so every rank draws the same Omega. */
 #define CORRLA_SEED_EXPLICIT 0x10u
+/* One-sweep power iteration: for a row-major f32 A with at most 512 columns, the pair
+ * Y = A X, Z = A^T Y of random_svd.rs:42-51 (and of the sketch, :31) is computed as Z = A^T (A X) from ONE pass over A
+ * with the 32-row tile of A held in LDS, wherever Y itself is not needed (the iterations without the in-loop thin-Q).
+ * Same result up to rounding (the intermediate stays in f32 registers instead of being rounded to memory).  Other
+ * shapes / dtypes / layouts ignore the flag.  The environment variable CORRLA_POWER_FUSED=1 sets it for every call. */
+#define CORRLA_POWER_FUSED 0x20u
 
 /*
  * Options block.  Zero-initialise, set struct_size = sizeof(corrla_opts).  NULL opts == defaults.

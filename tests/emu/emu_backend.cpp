@@ -144,6 +144,26 @@ class EmuDev {
         out.p[c * out.ld + j] = (T)(s * sc);
       }
   }
+  // same contract as HipDev::ata_fused: z = A^T (A x), the intermediate rounded to T like the kernel's f32 T tile
+  template <class T>
+  bool ata_fused_fits(const Big<T>& a, int64_t) const {
+    return sizeof(T) == 4 && a.cols <= 512 && a.cols >= 16 && a.rows >= 64 * 64;
+  }
+  template <class T>
+  void ata_fused(const Big<T>& a, const Skinny<T>& x, Skinny<T>& z) {
+    const ColBlocking cb = col_blocking(x.cols);
+    std::vector<double> acc((size_t)a.cols);
+    for (int64_t c = 0; c < cb.cols_alloc; ++c) {
+      std::fill(acc.begin(), acc.end(), 0.0);
+      for (int64_t i = 0; i < a.rows; ++i) {
+        double t = 0.0;
+        for (int64_t kk = 0; kk < a.cols; ++kk) t += (double)a.p[i * a.ld + kk] * (double)x.p[c * x.ld + kk];
+        const double tr = (double)(T)t;
+        for (int64_t kk = 0; kk < a.cols; ++kk) acc[(size_t)kk] += (double)a.p[i * a.ld + kk] * tr;
+      }
+      for (int64_t kk = 0; kk < a.cols; ++kk) z.p[c * z.ld + kk] = (T)acc[(size_t)kk];
+    }
+  }
   template <class T>
   void allreduce(T* p, size_t count) {
     if (g_nranks <= 1) return;

@@ -40,7 +40,7 @@ def _opts(omega, nt, l, dtype, seed=None, flags=0):
     return o, keep
 
 
-def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=False, qr=None):
+def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=False, qr=None, fused=False):
     e = emu()
     a = np.asarray(a)
     dtype = a.dtype
@@ -49,7 +49,7 @@ def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=Fal
     rs, cs = a.strides[0] // a.itemsize, a.strides[1] // a.itemsize
     nt = n if sharded else min(m, n)
     l = min(k + p, nt)
-    o, keep = _opts(omega, nt, l, dtype, seed, L.QR_HOUSEHOLDER if qr == "householder" else 0)
+    o, keep = _opts(omega, nt, l, dtype, seed, (L.QR_HOUSEHOLDER if qr == "householder" else 0) | (L.POWER_FUSED if fused else 0))
     u = np.empty((m, max(k, 1)), dtype=dtype, order="F")
     s = np.empty((max(k, 1), 1), dtype=dtype, order="F")
     vt = np.empty((max(k, 1), n), dtype=dtype, order="F")

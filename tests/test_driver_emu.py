@@ -311,3 +311,26 @@ def test_householder_flag_on_the_sharded_entry_point_takes_the_default_path():
     u1, s1, vt1 = emu_rsvd(a, 8, 2, 6, omega=om, sharded=True, qr="householder")
     u0, s0, vt0 = emu_rsvd(a, 8, 2, 6, omega=om, sharded=True)
     assert np.array_equal(s0, s1) and np.array_equal(u0, u1) and np.array_equal(vt0, vt1)
+
+
+@pytest.mark.parametrize("q", [0, 1, 2, 3, 5])
+def test_emu_one_sweep_power_iteration_schedule(q):
+    """SURVEY 8 f4 (CORRLA_POWER_FUSED): Z = A^T (A X) in one product wherever Y is not needed (the sketch and the
+    iterations without the in-loop thin-Q), the reference's own steps from there on.  Same factorisation as the
+    two-product schedule and as the oracle, for q below / at / above the i > 2 boundary."""
+    rng = np.random.default_rng(q)
+    m, n, k, p = 4200, 96, 10, 6          # >= 4096 rows: the fused kernel's domain; f32, row-major
+    a = (rng.standard_normal((m, n)) * (0.95 ** np.arange(n))).astype(np.float32)
+    om = rng.standard_normal((n, k + p)).astype(np.float32)
+    u1, s1, vt1 = emu_rsvd(a, k, q, p, omega=om, fused=True)
+    u0, s0, vt0 = emu_rsvd(a, k, q, p, omega=om, fused=False)
+    uo, so, vto = orc.random_svd(a.astype(np.float64), k, q, p, omega=om.astype(np.float64))
+    assert np.max(np.abs(s1 - s0)) <= 2e-5 * s0[0, 0] and np.max(np.abs(s1 - so)) <= 2e-5 * so[0, 0]
+    assert abs(orc.relerr(a, u1, s1, vt1) - orc.relerr(a, uo, so, vto)) <= 1e-5
+    assert orth_err(u1) < 2e-4 and orth_err(vt1.T) < 2e-4
+    # f64 and column-major inputs ignore the flag (outside the kernel's domain): identical to the plain schedule
+    a64 = a.astype(np.float64)
+    assert np.array_equal(emu_rsvd(a64, k, q, p, omega=om.astype(np.float64), fused=True)[1],
+                          emu_rsvd(a64, k, q, p, omega=om.astype(np.float64), fused=False)[1])
+    af = np.asfortranarray(a)
+    assert np.array_equal(emu_rsvd(af, k, q, p, omega=om, fused=True)[1], emu_rsvd(af, k, q, p, omega=om, fused=False)[1])

@@ -970,3 +970,57 @@ def test_f32_scale_invariance(ctx, scale):
     rec0 = (u0.astype(np.float64) * s0.ravel()) @ vt0.astype(np.float64)
     rec1 = (u1.astype(np.float64) * (s1.ravel() / scale)) @ vt1.astype(np.float64)
     assert np.linalg.norm(rec1 - rec0) <= 2e-3 * np.linalg.norm(rec0)
+
+
+# ---- one-sweep power iteration Z = A^T (A X) (CORRLA_POWER_FUSED, csrc/ata_kernels.hpp) -------------------
+@pytest.mark.parametrize("shape", [(4096, 512), (5000, 300), (9999, 64), (20011, 448), (4200, 16), (70000, 512)])
+@pytest.mark.parametrize("q", [0, 1, 2, 4])
+def test_one_sweep_power_iteration_matches_oracle(ctx, torch, shape, q):
+    """Row-major f32 A with n <= 512: every column-tile count, row counts that are not multiples of the 32-row tile,
+    n that is not a multiple of 64, q on both sides of the in-loop thin-Q boundary; shared Omega, vs the oracle and vs
+    the two-product schedule."""
+    m, n = shape
+    rng = np.random.default_rng(m + n + q)
+    # mild decay: (sigma_1 / sigma_l)^(2 q + 1) stays far below 1 / eps_f32, so f32 resolves every triplet for every q
+    # here (the reference re-orthonormalises only from its fourth iteration on)
+    a = (rng.standard_normal((m, n)) * (0.995 ** np.arange(n))).astype(np.float32)
+    k = max(1, min(n // 3, 70))
+    p = min(10, n - k)
+    om = rng.standard_normal((n, k + p)).astype(np.float32)
+    at = torch.tensor(a, device="cuda")
+    u1, s1, vt1 = ctx.rsvd(at, k, q, p, omega=om, fused=True)
+    u0, s0, vt0 = ctx.rsvd(at, k, q, p, omega=om)
+    uo, so, vto = orc.random_svd(a.astype(np.float64), k, q, p, omega=om.astype(np.float64))
+    u1n, s1n, vt1n = u1.cpu().numpy(), s1.cpu().numpy(), vt1.cpu().numpy()
+    assert np.max(np.abs(s1n - so)) <= 3e-5 * so[0, 0]
+    assert torch.allclose(s1, s0, rtol=0, atol=3e-5 * float(so[0, 0]))
+    assert abs(orc.relerr(a, u1n, s1n, vt1n) - orc.relerr(a, uo, so, vto)) <= 1e-5
+    assert orth_err(u1n) < 2e-4 and orth_err(vt1n.T) < 2e-4
+
+
+def test_one_sweep_is_ignored_outside_its_domain(ctx, torch, monkeypatch):
+    """f64, column-major or wide (n > 512) inputs take the two-product schedule whatever the flag says; the environment
+    switch CORRLA_POWER_FUSED=1 is the same as the flag; the sharded entry point accepts it too."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    a = torch.randn((6000, 200), dtype=torch.float32, device="cuda", generator=g)
+    om = np.random.default_rng(1).standard_normal((200, 30)).astype(np.float32)
+    for x in (a.double(), a.t().contiguous().t(), torch.randn((5000, 600), dtype=torch.float32, device="cuda", generator=g)):
+        o = om.astype(np.float64) if x.dtype == torch.float64 else om
+        if x.shape[1] == 600:
+            o = np.random.default_rng(2).standard_normal((600, 30)).astype(np.float32)
+        r1 = ctx.rsvd(x, 20, 2, 10, omega=o, fused=True)
+        r0 = ctx.rsvd(x, 20, 2, 10, omega=o)
+        assert torch.equal(r1[1], r0[1]) and torch.equal(r1[0], r0[0])
+    f1 = ctx.rsvd(a, 20, 2, 10, omega=om, fused=True)
+    monkeypatch.setenv("CORRLA_POWER_FUSED", "1")
+    f2 = ctx.rsvd(a, 20, 2, 10, omega=om)
+    monkeypatch.delenv("CORRLA_POWER_FUSED")
+    assert torch.equal(f1[1], f2[1]) and torch.equal(f1[0], f2[0])
+    import corrla_rs_amd as cr
+    c = cr.Context(0)
+    c.comm_init(cr.Context.unique_id(), 0, 1)
+    monkeypatch.setenv("CORRLA_FORCE_ALLREDUCE", "1")
+    f3 = c.rsvd_sharded(a, 20, 2, 10, omega=om, fused=True)
+    monkeypatch.delenv("CORRLA_FORCE_ALLREDUCE")
+    assert torch.equal(f3[1], f1[1])
+    c.close()

@@ -23,6 +23,7 @@ CONFIGS = {
     "C2x16tall": (1_048_576, 4096, torch.float32, 128, 2, 10),  # same size, tall
     "C2col": (16384, 16384, torch.float32, 128, 2, 10),
 }
+FUSED = os.environ.get("FUSED", "0") == "1"
 names = sys.argv[1:] or ["C1", "C3q2", "C4shard", "C5", "C2col"]
 ctx = cr.Context(0)
 for name in names:
@@ -32,19 +33,19 @@ for name in names:
         a = torch.empty((n, m), dtype=dt, device="cuda").t()   # column-major storage
     ctx.fill_normal(a, seed=20241008)
     for _ in range(2):
-        u, s, vt = ctx.rsvd(a, k, q, p, seed=1)
+        u, s, vt = ctx.rsvd(a, k, q, p, seed=1, fused=FUSED)
     torch.cuda.synchronize()
     reps = 3
     t0 = time.perf_counter()
     for _ in range(reps):
-        u, s, vt = ctx.rsvd(a, k, q, p, seed=1)
+        u, s, vt = ctx.rsvd(a, k, q, p, seed=1, fused=FUSED)
     torch.cuda.synchronize()
     dt_ms = (time.perf_counter() - t0) / reps * 1e3
     fl = cr.algorithmic_flops(m, n, k, q, p)
     tm = ctx.timings()
     eye = torch.eye(k, dtype=torch.float64, device="cuda")
     orth = (u.double().t() @ u.double() - eye).abs().max().item()
-    print(json.dumps({"config": name, "shape": [m, n], "dtype": str(dt), "k": k, "q": q, "p": p, "ms": round(dt_ms, 3),
+    print(json.dumps({"config": name + ("+fused" if FUSED else ""), "shape": [m, n], "dtype": str(dt), "k": k, "q": q, "p": p, "ms": round(dt_ms, 3),
                       "TFLOPs": round(fl / dt_ms / 1e9, 2), "orthU": orth, "s0": s[0, 0].item(),
                       "phases": {k_: round(v, 3) if isinstance(v, float) else v for k_, v in tm.items()}}), flush=True)
     del a, u, s, vt
