@@ -16,6 +16,7 @@ PCA_CENTER_COPY = 0x4
 QR_HOUSEHOLDER = 0x8
 SEED_EXPLICIT = 0x10
 POWER_FUSED = 0x20
+SHARD_COLS = 0x40
 UNIQUE_ID_BYTES = 128
 
 
@@ -51,6 +52,7 @@ def _sigs():
         pca = [vp, vp, i64, i64, i64, i64, i64, i64, i64, C.POINTER(Opts), vp, vp, vp, i64]
         s["corrla_pca_" + suf] = (C.c_int, pca)
         s["corrla_pca_dev_" + suf] = (C.c_int, pca)
+        s["corrla_pca_sharded_dev_" + suf] = (C.c_int, pca)
         pw = [vp, vp, i64, i64, i64, i64, i64, i64, C.POINTER(Opts), vp, i64]
         s["corrla_power_iter_" + suf] = (C.c_int, pw)
         s["corrla_power_iter_dev_" + suf] = (C.c_int, pw)

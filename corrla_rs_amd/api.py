@@ -162,7 +162,7 @@ class Context:
         del keep
         return u, s, vt
 
-    def _rsvd_torch(self, a, k, q, p, seed, omega, sharded=False, qr=None, fused=False):
+    def _rsvd_torch(self, a, k, q, p, seed, omega, sharded=False, qr=None, fused=False, shard_cols=False):
         import torch
         if a.dim() != 2:
             raise ValueError("a_mat must be 2-D")
@@ -177,9 +177,10 @@ class Context:
             a = a.contiguous()
         rs, cs = a.stride()
         suf = "f32" if a.dtype == torch.float32 else "f64"
-        nt = n if sharded else min(m, n)
+        nt = (m if shard_cols else n) if sharded else min(m, n)
         l = min(k + max(p, 0), nt)
-        o, keep = self._opts(seed, omega, nt, l, a.dtype, True, self._qr_flag(qr) | (L.POWER_FUSED if fused else 0))
+        o, keep = self._opts(seed, omega, nt, l, a.dtype, True, self._qr_flag(qr) | (L.POWER_FUSED if fused else 0) |
+                             (L.SHARD_COLS if shard_cols else 0))
         kk = max(k, 1)
         dev = a.device
         u = torch.empty((kk, m), dtype=a.dtype, device=dev).t()     # (m, k) column-major
@@ -193,12 +194,43 @@ class Context:
         del keep
         return u, s, vt
 
-    def rsvd_sharded(self, a_local, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, fused=False):
-        """Row-sharded random_svd: `a_local` holds this rank's rows of the tall
-        matrix as a torch CUDA tensor; returns (U_local, S, Vt) with S, Vt replicated."""
-        return self._rsvd_torch(a_local, int(n_rank), int(n_iters), int(n_oversamples), seed, omega, sharded=True, fused=fused)
+    def rsvd_sharded(self, a_local, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, fused=False, shard="rows"):
+        """Sharded random_svd, one process per GPU.  shard="rows": `a_local` holds this rank's
+        rows of a TALL matrix (torch CUDA tensor); returns (U_local, S, Vt) with S, Vt replicated.  shard="cols":
+        `a_local` holds this rank's COLUMNS of a FAT matrix; returns (U, S, Vt_local) with U, S replicated
+        (CORRLA_SHARD_COLS: the long side is what gets sharded, after the reference's fat -> tall transpose)."""
+        if shard not in ("rows", "cols"):
+            raise ValueError("shard must be 'rows' or 'cols'")
+        return self._rsvd_torch(a_local, int(n_rank), int(n_iters), int(n_oversamples), seed, omega, sharded=True, fused=fused,
+                                shard_cols=(shard == "cols"))
 
     # ---- PCA caller (pca_rsvd.rs:56-82) ---------------------------------------------------
+    def pca_sharded(self, x_local, rank, n_iter=None, n_oversamples=None, *, seed=None, omega=None, center=None):
+        """PcaRsvd::new on SAMPLE-sharded data (one process per GPU, `comm_init` done): `x_local` = this rank's samples
+        (CUDA tensor m_local x n_dim).  Returns (means, S, components), replicated on every rank."""
+        import torch
+        if not (_is_torch(x_local) and x_local.is_cuda):
+            raise ValueError("pca_sharded takes torch CUDA tensors")
+        cflags = {None: 0, "fused": L.PCA_CENTER_FUSED, "copy": L.PCA_CENTER_COPY}[center]
+        x = x_local if x_local.dtype in (torch.float32, torch.float64) else x_local.to(torch.float64)
+        m, n = x.shape
+        rank = int(rank)
+        q = 20 if n_iter is None else int(n_iter)
+        p = min(n, 10) if n_oversamples is None else int(n_oversamples)
+        rs, cs = x.stride()
+        l = min(rank + max(p, 0), n)
+        o, keep = self._opts(seed, omega, n, l, x.dtype, True, cflags)
+        kk = max(rank, 1)
+        means = torch.empty((1, n), dtype=x.dtype, device=x.device)
+        s = torch.empty((kk, 1), dtype=x.dtype, device=x.device)
+        comps = torch.empty((n, kk), dtype=x.dtype, device=x.device).t()
+        torch.cuda.current_stream(x.device).synchronize()
+        fn = getattr(self._lib, "corrla_pca_sharded_dev_" + ("f32" if x.dtype == torch.float32 else "f64"))
+        L.check(fn(self._h, x.data_ptr(), m, n, rs, cs, rank, q, p, C.byref(o) if o is not None else None,
+                   means.data_ptr(), s.data_ptr(), comps.data_ptr(), kk))
+        del keep
+        return means, s, comps
+
     def pca(self, x_mat, rank, n_iter=None, n_oversamples=None, *, seed=None, omega=None, center=None):
         """PcaRsvd::new(x, rank): returns (means (1, n), singular values (k, 1), components (k, n)).
         n_iter / n_oversamples default to the reference's hard-coded 20 / min(n_dim, 10) (pca_rsvd.rs:65-66).

@@ -138,8 +138,14 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
                        T* s, T* vt, int64_t ldvt, Timings* tm_out, bool profile) {
   if (!u || !s || !vt) throw Error(ST_EINVAL, "output pointer is NULL");
   validate_matrix(a, m, n, rs, cs);
+  // Sharded calls: the LONG side of the global matrix is split over the ranks.  Default: row shards of a tall matrix
+  // (local block m_local x n).  CORRLA_SHARD_COLS: column shards of a FAT matrix (local block m x n_local): the
+  // tall view of random_svd.rs:69-74 is then A^T, whose row shard is this block transposed -- a stride swap, no copy.
+  const bool shard_cols = sharded && opts && (opts->flags & CORRLA_SHARD_COLS) != 0;
+  if (!sharded && opts && (opts->flags & CORRLA_SHARD_COLS)) throw Error(ST_EINVAL, "CORRLA_SHARD_COLS is only valid for sharded entry points");
+  const int64_t short_side = shard_cols ? m : n;
   if (sharded) {
-    if (rank < 1 || rank > n) throw Error(ST_EINVAL, "rank must be in [1, n] for the row-sharded path");
+    if (rank < 1 || rank > short_side) throw Error(ST_EINVAL, "rank must be in [1, short side] for the sharded path");
     if (n_iter < 0 || n_oversamples < 0) throw Error(ST_EINVAL, "n_iter and n_oversamples must be >= 0");
     if (dev.nranks() < 1) throw Error(ST_ECOMM, "communicator not initialised");
   } else {
@@ -151,8 +157,9 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
   ro.sharded = sharded;
   if (!ro.seed_explicit && !ro.omega) ro.seed = dev.fresh_seed(/*rank_invariant=*/sharded);
   dev.begin_call();
-  TallA<T> ta = stage_input<Dev, T>(dev, host_ptrs, a, m, n, rs, cs, sharded);
-  const bool fat = !sharded && m < n;
+  TallA<T> ta = shard_cols ? stage_input<Dev, T>(dev, host_ptrs, a, n, m, cs, rs, true)
+                           : stage_input<Dev, T>(dev, host_ptrs, a, m, n, rs, cs, sharded);
+  const bool fat = sharded ? shard_cols : m < n;
   const int64_t k = rank;
   const int64_t l = std::min<int64_t>(rank + n_oversamples, ta.nt);  // random_svd.rs:77
   if (ro.omega && ro.omega_ld < ta.nt) throw Error(ST_EINVAL, "omega_ld < min(m, n)");
@@ -196,20 +203,30 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
 
 // PcaRsvd::new (pca_rsvd.rs:56-82): means, centring (implicit rank-1 corrections or a centred copy, see
 // CORRLA_PCA_CENTER_*), random_svd of the centred matrix; keeps S and V^T.
+// sharded: the SAMPLES (rows of x) are sharded over the ranks; means, S and the components come out replicated.  The
+// column means and every product with the centred matrix are linear in the rows, so they are all-reduced partial sums.
 template <class Dev, class T>
 inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank,
                       int64_t n_iter, int64_t n_oversamples, const corrla_opts* opts, T* means, T* s, T* comps,
-                      int64_t ldc, Timings* tm_out, bool profile) {
+                      int64_t ldc, Timings* tm_out, bool profile, bool sharded = false) {
   if (!means || !s || !comps) throw Error(ST_EINVAL, "output pointer is NULL");
   validate_matrix(x, m, n, rs, cs);
-  validate_rank(m, n, rank, n_iter, n_oversamples);
-  if (m < 2) throw Error(ST_EINVAL, "PCA needs at least two samples");
+  if (sharded) {
+    if (rank < 1 || rank > n) throw Error(ST_EINVAL, "rank must be in [1, n_dim] for the sample-sharded PCA");
+    if (n_iter < 0 || n_oversamples < 0) throw Error(ST_EINVAL, "n_iter and n_oversamples must be >= 0");
+    if (dev.nranks() < 1) throw Error(ST_ECOMM, "communicator not initialised");
+  } else {
+    validate_rank(m, n, rank, n_iter, n_oversamples);
+  }
   if (ldc < rank) throw Error(ST_EINVAL, "ldc < rank");
   RunOpts ro = parse_opts(opts, !host_ptrs);
-  if (!ro.seed_explicit && !ro.omega) ro.seed = dev.fresh_seed(false);
+  ro.sharded = sharded;
+  if (!ro.seed_explicit && !ro.omega) ro.seed = dev.fresh_seed(sharded);
   dev.begin_call();
-  TallA<T> ta = stage_input<Dev, T>(dev, host_ptrs, x, m, n, rs, cs, false);
-  const bool fat = m < n;  // the tall view is x^T: its ROWS are the data columns
+  const int64_t m_global = sharded ? dev.allreduce_sum_host(m) : m;  // every rank makes this call (rank-invariant)
+  if (m_global < 2) throw Error(ST_EINVAL, "PCA needs at least two samples");
+  TallA<T> ta = stage_input<Dev, T>(dev, host_ptrs, x, m, n, rs, cs, sharded);
+  const bool fat = !sharded && m < n;  // the tall view is x^T: its ROWS are the data columns
   // column means of x = (1/m) x^T 1: one pass of the transposed-GEMM kernel against a ones vector
   RsvdDriver<Dev, T> drv(dev, profile);
   const int64_t samples_dim_tall = fat ? ta.nt : ta.mt;  // n_samples as a dimension of the tall view
@@ -217,10 +234,10 @@ inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n
   dev.fill_const(ones.p, samples_dim_tall, (T)1);
   Skinny<T> mu = dev.template alloc_skinny<T>(fat ? ta.mt : ta.nt, 1);
   T* inv_m = dev.template alloc_scalar<T>(1);
-  const T inv_m_host = (T)(1.0 / (double)m);
+  const T inv_m_host = (T)(1.0 / (double)m_global);
   dev.store_values(&inv_m_host, (int64_t)1, inv_m, /*dst_is_host=*/false);
   if (!fat)
-    drv.at_times(ta, ones, mu, inv_m, false);  // mu (n) = x^T 1 / m
+    drv.at_times(ta, ones, mu, inv_m, sharded);  // mu (n) = x^T 1 / m (all-reduced partial sums when sharded)
   else
     drv.a_times(ta, ones, mu, inv_m);          // tall view = x^T (n x m): mu (n) = x^T 1 / m
   TallA<T> tc = ta;

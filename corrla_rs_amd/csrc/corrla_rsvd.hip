@@ -68,11 +68,13 @@ corrla_status rsvd_c(corrla_ctx* ctx, bool host, bool sharded, const T* a, int64
 }
 template <class T>
 corrla_status pca_c(corrla_ctx* ctx, bool host, const T* x, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank,
-                    int64_t n_iter, int64_t p, const corrla_opts* o, T* means, T* s, T* comps, int64_t ldc) {
+                    int64_t n_iter, int64_t p, const corrla_opts* o, T* means, T* s, T* comps, int64_t ldc,
+                    bool sharded = false) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);
     locked_call(c, [&] {
-      pca_entry<HipDev, T>(c->dev, host, x, m, n, rs, cs, rank, n_iter, p, o, means, s, comps, ldc, &c->last, c->profile);
+      pca_entry<HipDev, T>(c->dev, host, x, m, n, rs, cs, rank, n_iter, p, o, means, s, comps, ldc, &c->last, c->profile,
+                           sharded);
     });
   });
 }
@@ -204,6 +206,11 @@ CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings*
                                                 int64_t cs, int64_t rank, int64_t n_iter, int64_t p,                   \
                                                 const corrla_opts* o, T* means, T* s, T* comps, int64_t ldc) {         \
     return pca_c<T>(ctx, false, x, m, n, rs, cs, rank, n_iter, p, o, means, s, comps, ldc);                            \
+  }                                                                                                                    \
+  CORRLA_API corrla_status corrla_pca_sharded_dev_##SUF(corrla_ctx* ctx, const T* x, int64_t m, int64_t n, int64_t rs,  \
+                                                        int64_t cs, int64_t rank, int64_t n_iter, int64_t p,           \
+                                                        const corrla_opts* o, T* means, T* s, T* comps, int64_t ldc) { \
+    return pca_c<T>(ctx, false, x, m, n, rs, cs, rank, n_iter, p, o, means, s, comps, ldc, true);                      \
   }                                                                                                                    \
   CORRLA_API corrla_status corrla_power_iter_##SUF(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,     \
                                         int64_t width, int64_t n_iter, const corrla_opts* o, T* q, int64_t ldq) {      \

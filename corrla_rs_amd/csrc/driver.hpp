@@ -163,8 +163,8 @@ struct RsvdDriver {
     else
       dev.gemm_nn(a.mem, y, z, scale_dev);
     if (a.mu_short || a.mu_tall) {
-      if (sharded) throw Error(ST_EINVAL, "internal: implicit centring is not available for sharded inputs");
-      // (A - 1 mu^T)^T Y = A^T Y - mu (1^T Y);  (A - mu 1^T)^T Y = A^T Y - 1 (mu^T Y)
+      // (A - 1 mu^T)^T Y = A^T Y - mu (1^T Y);  (A - mu 1^T)^T Y = A^T Y - 1 (mu^T Y).  Row-sharded: the correction is
+      // linear in the rows, so every rank corrects its own partial product and the all-reduce below sums both parts.
       T* v = dev.template alloc_scalar<T>((int)y.cols_alloc);
       dev.weighted_colsum(y, a.mt, a.mu_tall, v);
       dev.rank1_sub(z, a.nt, a.mu_short, v, scale_dev);

@@ -274,6 +274,8 @@ class HipDev {
     if (s.ld > rows)
       CORRLA_HIP(hipMemset2DAsync(s.p + rows, (size_t)s.ld * sizeof(T), 0, (size_t)(s.ld - rows) * sizeof(T), (size_t)s.cols_alloc,
                                   stream));
+    // the padding columns too: an uneven column blocking does not write its all-zero tail tile
+    if (s.cols_alloc > cols) memset_zero(s.p + cols * s.ld, (size_t)(s.cols_alloc - cols) * s.ld * sizeof(T));
     return s;
   }
   double* alloc_f64(int n) {
@@ -1217,6 +1219,21 @@ class HipDev {
     else
       hipLaunchKernelGGL((k::gemm_nn_kernel<T, MW, NT>), grid, block, lds, stream, a);
   }
+  template <class T>
+  void launch_nt(bool tn, int mw, int nt, dim3 grid, const k::GemmArgs<T>& a) {
+    switch (nt) {
+      case 1: launch_mw<T, 1>(tn, mw, grid, a); break;
+      case 2: launch_mw<T, 2>(tn, mw, grid, a); break;
+      case 3: launch_mw<T, 3>(tn, mw, grid, a); break;
+      case 4: launch_mw<T, 4>(tn, mw, grid, a); break;
+      case 5: launch_mw<T, 5>(tn, mw, grid, a); break;
+      case 6: launch_mw<T, 6>(tn, mw, grid, a); break;
+      case 7: launch_mw<T, 7>(tn, mw, grid, a); break;
+      case 8: launch_mw<T, 8>(tn, mw, grid, a); break;
+      case 9: launch_mw<T, 9>(tn, mw, grid, a); break;
+      default: throw Error(ST_EINVAL, "internal: bad column blocking");
+    }
+  }
   template <class T, int NT>
   void launch_alias(dim3 grid, const k::GemmArgs<T>& a) {
     const dim3 block(64 * (4 + k::kLoaders));
@@ -1248,7 +1265,11 @@ class HipDev {
     const int tiles_total = (int)tiles64;
     if (x.ld < (int64_t)tiles_total * KT) throw Error(ST_EINVAL, "internal: skinny leading dimension too small");
     int mw = 1, nsplit = 1;
-    choose_geometry(tn, outer_n, cb.nblk, tiles_total, &mw, &nsplit);
+    // an uneven column blocking (see below) runs its wide and its narrow blocks as two launches: each must fill the
+    // chip by itself, so the reduction split is sized for the blocks of ONE launch
+    const int n_wide0 = cb.tiles - cb.nblk * (cb.nt - 1);
+    const bool uneven0 = cb.nblk > 1 && n_wide0 < cb.nblk && cb.nt >= 2 && !env_int("CORRLA_EVEN_BLOCKS", 0);
+    choose_geometry(tn, outer_n, uneven0 ? std::max(1, std::min(n_wide0, cb.nblk - n_wide0)) : cb.nblk, tiles_total, &mw, &nsplit);
     // Gram matrix G = Y^T Y: both operands are the same memory and one outer tile (MW = 2: 128 indices) holds every
     // column -> the aliased instantiation stages Y once per tile
     const bool alias = !tn && (const void*)r.p == (const void*)x.p && r.ld == x.ld && cb.nblk == 1 && outer_n <= 128 &&
@@ -1271,7 +1292,11 @@ class HipDev {
     a.x_ld = x.ld;
     a.out = out.p;
     a.out_ld = out.ld;
-    a.out_cols = out.external ? out.cols : cb.cols_alloc;
+    // columns this product may write: a caller's buffer has exactly `cols`; an uneven column blocking (below) never
+    // computes the all-zero tail tile, which therefore stays as allocated (zero)
+    const int n_wide = cb.tiles - cb.nblk * (cb.nt - 1);  // column blocks that really have cb.nt tiles
+    const bool uneven = !alias && cb.nblk > 1 && n_wide < cb.nblk && cb.nt >= 2 && !env_int("CORRLA_EVEN_BLOCKS", 0);
+    a.out_cols = out.external ? out.cols : (uneven ? (int64_t)cb.tiles * 16 : cb.cols_alloc);
     a.scale = scale_dev;
     a.zero = (const T*)zero_page_;
     a.tiles_total = tiles_total;
@@ -1283,7 +1308,17 @@ class HipDev {
     if (nsplit > 1) a.slab = (T*)alloc_bytes((size_t)nsplit * (size_t)a.slab_stride * sizeof(T));
     dim3 grid((unsigned)outer_tiles, (unsigned)cb.nblk, (unsigned)nsplit);
     check_grid(grid);
-    if (alias) {
+    a.col_base = 0;
+    // Uneven column blocking: `tiles` 16-column tiles over nblk blocks need not all be cb.nt wide -- 17 tiles (l = 266)
+    // are 9 + 8, not 9 + 9: the narrower blocks run the next-smaller instantiation in a second launch and skip the
+    // all-zero padding tile (5.5 % of the MFMA work of every tall product at l = 266).
+    if (uneven) {
+      dim3 g1((unsigned)outer_tiles, (unsigned)n_wide, (unsigned)nsplit);
+      dim3 g2((unsigned)outer_tiles, (unsigned)(cb.nblk - n_wide), (unsigned)nsplit);
+      launch_nt<T>(tn, mw, cb.nt, g1, a);
+      a.col_base = (int64_t)n_wide * cb.nt * 16;
+      launch_nt<T>(tn, mw, cb.nt - 1, g2, a);
+    } else if (alias) {
       switch (cb.nt) {
         case 1: launch_alias<T, 1>(grid, a); break;
         case 2: launch_alias<T, 2>(grid, a); break;
@@ -1294,18 +1329,8 @@ class HipDev {
         case 7: launch_alias<T, 7>(grid, a); break;
         default: launch_alias<T, 8>(grid, a); break;
       }
-    } else
-    switch (cb.nt) {
-      case 1: launch_mw<T, 1>(tn, mw, grid, a); break;
-      case 2: launch_mw<T, 2>(tn, mw, grid, a); break;
-      case 3: launch_mw<T, 3>(tn, mw, grid, a); break;
-      case 4: launch_mw<T, 4>(tn, mw, grid, a); break;
-      case 5: launch_mw<T, 5>(tn, mw, grid, a); break;
-      case 6: launch_mw<T, 6>(tn, mw, grid, a); break;
-      case 7: launch_mw<T, 7>(tn, mw, grid, a); break;
-      case 8: launch_mw<T, 8>(tn, mw, grid, a); break;
-      case 9: launch_mw<T, 9>(tn, mw, grid, a); break;
-      default: throw Error(ST_EINVAL, "internal: bad column blocking");
+    } else {
+      launch_nt<T>(tn, mw, cb.nt, grid, a);
     }
     CORRLA_HIP(hipGetLastError());
     if (nsplit >= 8) {

@@ -111,6 +111,7 @@ struct GemmArgs {
   T* out;             // skinny result, column-major
   int64_t out_ld;
   int64_t out_cols;   // columns of `out` that may be written (the padded column count, or fewer for a caller's buffer)
+  int64_t col_base;   // first column of this launch's column blocks (uneven column blockings take two launches)
   T* slab;            // partial results when nsplit > 1: slab[z][col][outer]
   int64_t slab_stride;
   const T* scale;     // optional device scalar applied to the result (nsplit == 1 only)
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row0 = (int64_t)blockIdx.x * outer_tile(MW);
-  const int64_t col0 = (int64_t)blockIdx.y * (NT * 16);
+  const int64_t col0 = g.col_base + (int64_t)blockIdx.y * (NT * 16);
   const int t_begin = blockIdx.z * g.tiles_per_split;
   const int t_end = min(t_begin + g.tiles_per_split, g.tiles_total);
   const int nk = t_end - t_begin;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n0 = (int64_t)blockIdx.x * outer_tile(MW);
-  const int64_t col0 = (int64_t)blockIdx.y * (NT * 16);
+  const int64_t col0 = g.col_base + (int64_t)blockIdx.y * (NT * 16);
   const int t_begin = blockIdx.z * g.tiles_per_split;
   const int t_end = min(t_begin + g.tiles_per_split, g.tiles_total);
   const int nk = t_end - t_begin;

@@ -80,6 +80,11 @@ typedef enum corrla_status {
  * Same result up to rounding (the intermediate stays in f32 registers instead of being rounded to memory).  Other
  * shapes / dtypes / layouts ignore the flag.  The environment variable CORRLA_POWER_FUSED=1 sets it for every call. */
 #define CORRLA_POWER_FUSED 0x20u
+/* corrla_rsvd_sharded_dev_*: the local block is a COLUMN shard (m x n_local) of a fat matrix (m < sum of n_local)
+ * instead of a row shard of a tall one.  The algorithm works on the tall view A^T (random_svd.rs:69-74), whose row shard
+ * is this block transposed (a stride swap).  Outputs: U m x rank and S replicated on every rank, Vt rank x n_local =
+ * this rank's columns of V^T.  opts->omega, when given, is m x l (the short side). */
+#define CORRLA_SHARD_COLS 0x40u
 
 /*
  * Options block.  Zero-initialise, set struct_size = sizeof(corrla_opts).  NULL opts == defaults.
@@ -184,6 +189,16 @@ CORRLA_API corrla_status corrla_pca_dev_f64(corrla_ctx* ctx, const double* x, in
                                             int64_t row_stride, int64_t col_stride, int64_t rank, int64_t n_iter,
                                             int64_t n_oversamples, const corrla_opts* opts, double* means, double* s,
                                             double* components, int64_t ldc);
+/* Sample-sharded PCA (one process per GPU, communicator from corrla_ctx_comm_init): x holds THIS rank's samples
+ * (m_local x n_dim); the column means are all-reduced partial sums over the global sample count, and both centring
+ * forms work unchanged (the rank-1 corrections of the fused form are linear in the rows: each rank corrects its own
+ * partial product before the all-reduce).  means, s and components come out replicated on every rank. */
+CORRLA_API corrla_status corrla_pca_sharded_dev_f32(corrla_ctx* ctx, const float* x, int64_t m_local, int64_t n, int64_t row_stride,
+                                         int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
+                                         const corrla_opts* opts, float* means, float* s, float* components, int64_t ldc);
+CORRLA_API corrla_status corrla_pca_sharded_dev_f64(corrla_ctx* ctx, const double* x, int64_t m_local, int64_t n, int64_t row_stride,
+                                         int64_t col_stride, int64_t rank, int64_t n_iter, int64_t n_oversamples,
+                                         const corrla_opts* opts, double* means, double* s, double* components, int64_t ldc);
 
 /* ---- the range finder: power_iter ---------------------------------------------------
  * Replaces  pub fn power_iter<T>(a_mat: MatRef<T>, omega_rank, n_iter) -> Mat<T>

@@ -30,6 +30,7 @@ pub const CORRLA_PCA_CENTER_COPY: u32 = 0x4;
 pub const CORRLA_QR_HOUSEHOLDER: u32 = 0x8;
 pub const CORRLA_SEED_EXPLICIT: u32 = 0x10;
 pub const CORRLA_POWER_FUSED: u32 = 0x20;
+pub const CORRLA_SHARD_COLS: u32 = 0x40;
 
 extern "C" {
     fn corrla_ctx_create(device: c_int, out: *mut *mut c_void) -> c_int;

@@ -38,9 +38,27 @@ def main():
     lo, hi = rank * m // world, (rank + 1) * m // world
     if "splits" in d.files:          # explicit (uneven) row split: splits[r] .. splits[r + 1]
         lo, hi = int(d["splits"][rank]), int(d["splits"][rank + 1])
+    if "pca" in d.files and int(d["pca"]) == 1:
+        from tests.emu_harness import emu_pca
+        for dtype in (np.float64, np.float32):
+            for center in ("fused", "copy"):
+                a_loc = np.ascontiguousarray(a[lo:hi].astype(dtype))
+                means, s, comps = emu_pca(a_loc, k, q, p, omega=omega.astype(dtype), center=center, sharded=True)
+                np.savez(os.path.join(out_dir, f"pca_{np.dtype(dtype).name}_{center}_rank{rank}.npz"), means=means, s=s, comps=comps,
+                         n_allreduce=calls["n"])
+                calls["n"] = 0
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    shard_cols = "shard_cols" in d.files and int(d["shard_cols"]) == 1
     for dtype in (np.float64, np.float32):
-        a_loc = np.ascontiguousarray(a[lo:hi].astype(dtype))
-        u, s, vt = emu_rsvd(a_loc, k, q, p, omega=omega.astype(dtype), sharded=True)
+        if shard_cols:     # fat matrix, this rank's COLUMNS (lo/hi index the columns)
+            n = a.shape[1]
+            lo, hi = (int(d["splits"][rank]), int(d["splits"][rank + 1])) if "splits" in d.files else (rank * n // world, (rank + 1) * n // world)
+            a_loc = np.ascontiguousarray(a[:, lo:hi].astype(dtype))
+        else:
+            a_loc = np.ascontiguousarray(a[lo:hi].astype(dtype))
+        u, s, vt = emu_rsvd(a_loc, k, q, p, omega=omega.astype(dtype), sharded=True, shard_cols=shard_cols)
         np.savez(os.path.join(out_dir, f"out_{np.dtype(dtype).name}_rank{rank}.npz"), u=u, s=s, vt=vt, lo=lo, hi=hi,
                  n_allreduce=calls["n"])
         calls["n"] = 0

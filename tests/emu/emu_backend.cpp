@@ -558,6 +558,14 @@ EMU_API void corrla_emu_set_comm(emu_allreduce_fn fn, int nranks) {
       pca_entry<EmuDev, T>(dev, true, a, m, n, rs, cs, rank, n_iter, p, o, means, s, comps, ldc, nullptr, false);      \
     });                                                                                                                \
   }                                                                                                                    \
+  EMU_API int corrla_emu_pca_sharded_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank,     \
+                                           int64_t n_iter, int64_t p, const corrla_opts* o, T* means, T* s, T* comps,  \
+                                           int64_t ldc) {                                                              \
+    return guarded([&] {                                                                                               \
+      EmuDev dev;                                                                                                      \
+      pca_entry<EmuDev, T>(dev, true, a, m, n, rs, cs, rank, n_iter, p, o, means, s, comps, ldc, nullptr, false, true); \
+    });                                                                                                                \
+  }                                                                                                                    \
   EMU_API int corrla_emu_power_iter_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t width,             \
                                   int64_t n_iter, const corrla_opts* o, T* q, int64_t ldq) {                           \
     return guarded([&] {                                                                                               \

@@ -40,16 +40,17 @@ def _opts(omega, nt, l, dtype, seed=None, flags=0):
     return o, keep
 
 
-def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=False, qr=None, fused=False):
+def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=False, qr=None, fused=False, shard_cols=False):
     e = emu()
     a = np.asarray(a)
     dtype = a.dtype
     suf = "f32" if dtype == np.float32 else "f64"
     m, n = a.shape
     rs, cs = a.strides[0] // a.itemsize, a.strides[1] // a.itemsize
-    nt = n if sharded else min(m, n)
+    nt = (m if shard_cols else n) if sharded else min(m, n)
     l = min(k + p, nt)
-    o, keep = _opts(omega, nt, l, dtype, seed, (L.QR_HOUSEHOLDER if qr == "householder" else 0) | (L.POWER_FUSED if fused else 0))
+    o, keep = _opts(omega, nt, l, dtype, seed, (L.QR_HOUSEHOLDER if qr == "householder" else 0) | (L.POWER_FUSED if fused else 0) |
+                    (L.SHARD_COLS if shard_cols else 0))
     u = np.empty((m, max(k, 1)), dtype=dtype, order="F")
     s = np.empty((max(k, 1), 1), dtype=dtype, order="F")
     vt = np.empty((max(k, 1), n), dtype=dtype, order="F")
@@ -121,14 +122,14 @@ def emu_fill_normal(rows, cols, seed, dtype=np.float64, row0=0, global_cols=None
     return out
 
 
-def emu_pca(x, rank, q, p, omega=None, center=None):
+def emu_pca(x, rank, q, p, omega=None, center=None, sharded=False):
     """center: None (library default), "fused" (CORRLA_PCA_CENTER_FUSED = 0x2) or "copy" (0x4)."""
     e = emu()
     x = np.asarray(x)
     suf = "f32" if x.dtype == np.float32 else "f64"
     m, n = x.shape
     rs, cs = x.strides[0] // x.itemsize, x.strides[1] // x.itemsize
-    nt = min(m, n)
+    nt = n if sharded else min(m, n)
     l = min(rank + p, nt)
     o, keep = _opts(omega, nt, l, x.dtype)
     if center is not None:
@@ -139,7 +140,7 @@ def emu_pca(x, rank, q, p, omega=None, center=None):
     s = np.empty((rank, 1), dtype=x.dtype)
     comps = np.empty((rank, n), dtype=x.dtype, order="F")
     i64 = C.c_int64
-    rc = getattr(e, "corrla_emu_pca_" + suf)(C.c_void_p(x.ctypes.data), i64(m), i64(n), i64(rs), i64(cs), i64(rank), i64(q),
+    rc = getattr(e, ("corrla_emu_pca_sharded_" if sharded else "corrla_emu_pca_") + suf)(C.c_void_p(x.ctypes.data), i64(m), i64(n), i64(rs), i64(cs), i64(rank), i64(q),
                                              i64(p), C.byref(o) if o is not None else None, C.c_void_p(means.ctypes.data),
                                              C.c_void_p(s.ctypes.data), C.c_void_p(comps.ctypes.data), i64(rank))
     if rc != 0:

@@ -1024,3 +1024,34 @@ def test_one_sweep_is_ignored_outside_its_domain(ctx, torch, monkeypatch):
     monkeypatch.delenv("CORRLA_FORCE_ALLREDUCE")
     assert torch.equal(f3[1], f1[1])
     c.close()
+
+
+def test_sharded_completeness_world_size_1(torch, monkeypatch):
+    """Column-sharded fat input (CORRLA_SHARD_COLS) and sample-sharded PCA (corrla_pca_sharded_dev_*) on a one-rank RCCL
+    communicator with every all-reduce issued: equal to the unsharded entry points (the N = 2 exchange logic runs on the
+    CPU through the same driver: tests/test_sharded_gloo.py)."""
+    import corrla_rs_amd as cr
+    c = cr.Context(0)
+    c.comm_init(cr.Context.unique_id(), 0, 1)
+    monkeypatch.setenv("CORRLA_FORCE_ALLREDUCE", "1")
+    g = torch.Generator(device="cuda").manual_seed(6)
+    for dt, tol in ((torch.float64, 1e-10), (torch.float32, 3e-5)):
+        a = torch.randn((120, 5000), dtype=dt, device="cuda", generator=g)             # fat
+        om = np.random.default_rng(3).standard_normal((120, 26))
+        u1, s1, vt1 = c.rsvd_sharded(a, 16, 3, 10, omega=om, shard="cols")
+        u0, s0, vt0 = c.rsvd(a, 16, 3, 10, omega=om)
+        assert u1.shape == (120, 16) and vt1.shape == (16, 5000)
+        assert torch.allclose(s1, s0, rtol=0, atol=tol * float(s0[0, 0]))
+        r1 = (u1.double() * s1.double().ravel()) @ vt1.double()
+        r0 = (u0.double() * s0.double().ravel()) @ vt0.double()
+        assert float((r1 - r0).norm() / r0.norm()) < 100 * tol
+        x = torch.randn((3000, 64), dtype=dt, device="cuda", generator=g) * torch.linspace(2, 0.2, 64, device="cuda", dtype=dt) + 1.5
+        omp = np.random.default_rng(4).standard_normal((64, 16))
+        for center in ("fused", "copy"):
+            m1, sp1, c1 = c.pca_sharded(x, 6, omega=omp, center=center)
+            m0, sp0, c0 = c.pca(x, 6, omega=omp, center=center)
+            assert torch.allclose(m1, m0, atol=tol * 10) and torch.allclose(sp1, sp0, rtol=0, atol=tol * 10 * float(sp0[0, 0]))
+            assert float((c1.double().t() @ c1.double() - c0.double().t() @ c0.double()).norm()) < 1e3 * tol
+    with pytest.raises(ValueError):
+        c.rsvd_sharded(a, 16, 3, 10, shard="diagonal")
+    c.close()

@@ -79,3 +79,65 @@ def test_row_sharded_rank_deficient_with_a_shard_shorter_than_l():
             assert np.max(np.abs(u.T @ u - np.eye(k))) < 100 * tol        # orthonormal completion across the shards
             assert np.max(np.abs(vt @ vt.T - np.eye(k))) < 100 * tol
             assert np.linalg.norm((u * s.ravel()) @ vt - a) <= 100 * tol * np.linalg.norm(a)
+
+
+@pytest.mark.timeout(300)
+def test_column_sharded_fat_matrix_world2():
+    """CORRLA_SHARD_COLS: a FAT matrix sharded along its long side (columns).  The reference works on the tall view A^T
+    (random_svd.rs:69-74); every rank passes its m x n_local block, gets U and S replicated and its own columns of Vt.
+    Uneven shards; result equal to the single-rank call on the whole fat matrix with the same Omega (m x l)."""
+    rng = np.random.default_rng(11)
+    m, n, k, q, p = 40, 301, 8, 4, 6
+    a = rng.standard_normal((m, n)) * (0.93 ** np.arange(m))[:, None]
+    omega = rng.standard_normal((m, k + p))
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "input.npz"), A=a, omega=omega, k=k, q=q, p=p, splits=np.array([0, 100, 301]), shard_cols=1)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29545")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", "29545", os.path.join(ROOT, "tests", "_sharded_worker.py"), td]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        for dtype, tol in ((np.float64, 1e-10), (np.float32, 5e-5)):
+            name = np.dtype(dtype).name
+            outs = [np.load(os.path.join(td, f"out_{name}_rank{r_}.npz")) for r_ in range(2)]
+            assert outs[0]["u"].shape == (m, k) and outs[0]["vt"].shape == (k, 100) and outs[1]["vt"].shape == (k, 201)
+            assert np.array_equal(outs[0]["u"], outs[1]["u"]) and np.array_equal(outs[0]["s"], outs[1]["s"])
+            u, s = outs[0]["u"], outs[0]["s"]
+            vt = np.hstack([o["vt"] for o in outs])
+            u1, s1, vt1 = emu_rsvd(a.astype(dtype), k, q, p, omega=omega.astype(dtype))
+            assert np.max(np.abs(s - s1)) <= tol * s1[0, 0]
+            rec = (u.astype(np.float64) * s.ravel()) @ vt
+            rec1 = (u1.astype(np.float64) * s1.ravel()) @ vt1
+            assert np.linalg.norm(rec - rec1) <= 100 * tol * np.linalg.norm(rec1)
+            uo, so, vto = orc.random_svd(a.astype(dtype), k, q, p, omega=omega.astype(dtype))
+            assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-5
+
+
+@pytest.mark.timeout(300)
+def test_sample_sharded_pca_world2():
+    """corrla_pca_sharded_*: samples sharded over two ranks (uneven), fused and copy centring: means all-reduced over
+    the global sample count, the rank-1 corrections of the fused form applied per rank before each all-reduce.  Result
+    equal to the single-rank PCA of the whole matrix and to the oracle (pca_rsvd.rs:56-82)."""
+    from tests.emu_harness import emu_pca
+    rng = np.random.default_rng(21)
+    m, n, k, q, p = 211, 24, 5, 4, 8
+    x = rng.standard_normal((m, n)) * (0.8 ** np.arange(n)) + rng.standard_normal((1, n)) * 2.0
+    omega = rng.standard_normal((n, k + p))
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "input.npz"), A=x, omega=omega, k=k, q=q, p=p, splits=np.array([0, 60, 211]), pca=1)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tests", "_sharded_worker.py"), td]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        for dtype, tol in ((np.float64, 1e-9), (np.float32, 2e-4)):
+            name = np.dtype(dtype).name
+            m1, s1, c1 = emu_pca(x.astype(dtype), k, q, p, omega=omega.astype(dtype), center="copy")
+            for center in ("fused", "copy"):
+                outs = [np.load(os.path.join(td, f"pca_{name}_{center}_rank{r_}.npz")) for r_ in range(2)]
+                for f in ("means", "s", "comps"):
+                    assert np.array_equal(outs[0][f], outs[1][f]), (center, f)       # replicated
+                assert np.allclose(outs[0]["means"], x.mean(axis=0, keepdims=True), atol=tol * 10)
+                assert np.allclose(outs[0]["s"], s1, rtol=tol, atol=tol * s1[0, 0])
+                cg = outs[0]["comps"].astype(np.float64)
+                assert np.linalg.norm(cg.T @ cg - c1.astype(np.float64).T @ c1.astype(np.float64)) < 200 * tol
