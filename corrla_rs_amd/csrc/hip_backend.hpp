@@ -1268,7 +1268,9 @@ class HipDev {
     // an uneven column blocking (see below) runs its wide and its narrow blocks as two launches: each must fill the
     // chip by itself, so the reduction split is sized for the blocks of ONE launch
     const int n_wide0 = cb.tiles - cb.nblk * (cb.nt - 1);
-    const bool uneven0 = cb.nblk > 1 && n_wide0 < cb.nblk && cb.nt >= 2 && !env_int("CORRLA_EVEN_BLOCKS", 0);
+    // (only where it pays: the second launch costs ~10 us, the skipped tile 1/18 of a product's time)
+    const bool uneven0 = cb.nblk > 1 && n_wide0 < cb.nblk && cb.nt >= 2 && !env_int("CORRLA_EVEN_BLOCKS", 0) &&
+                         (double)outer_n * (double)red_n * (double)cb.cols_alloc >= 1.0e10;
     choose_geometry(tn, outer_n, uneven0 ? std::max(1, std::min(n_wide0, cb.nblk - n_wide0)) : cb.nblk, tiles_total, &mw, &nsplit);
     // Gram matrix G = Y^T Y: both operands are the same memory and one outer tile (MW = 2: 128 indices) holds every
     // column -> the aliased instantiation stages Y once per tile
@@ -1295,7 +1297,7 @@ class HipDev {
     // columns this product may write: a caller's buffer has exactly `cols`; an uneven column blocking (below) never
     // computes the all-zero tail tile, which therefore stays as allocated (zero)
     const int n_wide = cb.tiles - cb.nblk * (cb.nt - 1);  // column blocks that really have cb.nt tiles
-    const bool uneven = !alias && cb.nblk > 1 && n_wide < cb.nblk && cb.nt >= 2 && !env_int("CORRLA_EVEN_BLOCKS", 0);
+    const bool uneven = !alias && uneven0;
     a.out_cols = out.external ? out.cols : (uneven ? (int64_t)cb.tiles * 16 : cb.cols_alloc);
     a.scale = scale_dev;
     a.zero = (const T*)zero_page_;
