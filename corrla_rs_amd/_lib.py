@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libcorrla_rsvd.so")
+# CORRLA_RSVD_LIB: another build of the same library (kernel A/B measurements)
+LIB_PATH = os.environ.get("CORRLA_RSVD_LIB") or os.path.join(PKG, "lib", "libcorrla_rsvd.so")
 
 i64, u64, u32, i32, dbl, flt = C.c_int64, C.c_uint64, C.c_uint32, C.c_int32, C.c_double, C.c_float
 vp = C.c_void_p

@@ -20,6 +20,7 @@
 #include "tsqr_kernels.hpp"
 #include "jacobi_mc_kernels.hpp"
 #include "ata_kernels.hpp"
+#include "tall_kernels.hpp"
 
 namespace corrla {
 
@@ -88,17 +89,9 @@ class HipDev {
     set_tsqr_attrs<double>();
     set_jmc_attrs<float>();
     set_jmc_attrs<double>();
-    {
-      const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<1>, attr, k::ata_lds_bytes(1)));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<2>, attr, k::ata_lds_bytes(2)));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<3>, attr, k::ata_lds_bytes(3)));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<4>, attr, k::ata_lds_bytes(4)));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<5>, attr, k::ata_lds_bytes(5)));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<6>, attr, k::ata_lds_bytes(6)));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<7>, attr, k::ata_lds_bytes(7)));
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<8>, attr, k::ata_lds_bytes(8)));
-    }
+    ata_set_attrs<2>();
+    ata_set_attrs<4>();
+    ata_set_attrs<8>();
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<float>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::jacobi_svd_split_kernel<double>,
@@ -117,6 +110,8 @@ class HipDev {
     no_device_chol_ = env_int("CORRLA_HOST_CHOL", 0) != 0;
     jmc_min_l_ = env_int("CORRLA_JMC_MIN_L", 96);  // below: the single-workgroup ring kernel + replay is as fast (one launch)
     jmc_max_b_ = std::min(32, std::max(2, env_int("CORRLA_JMC_MAX_B", 24)));
+    tall_min_rows_ = env_int("CORRLA_TALL_MIN_ROWS", 65536);  // 0: the general kernels everywhere
+    persist_max_tiles_ = env_int("CORRLA_GEMM_PERSIST_TILES", 16);  // 0: one workgroup per outer tile everywhere
     gemm_debug_flags_ = env_int("CORRLA_GEMM_DEBUG", 0);  // timing-only ablations, results are wrong
   }
   ~HipDev() {
@@ -308,11 +303,30 @@ class HipDev {
     launch_gemm<T>(true, r, x, out, scale_dev, r.cols, r.rows);
   }
 
-  // ---- one-sweep Z' = A^T (A Z) (ata_kernels.hpp): row-major f32 A with n <= 512 ----------------
+  // ---- one-sweep Z' = A^T (A Z) (ata_kernels.hpp): row-major f32 A with n <= 512, l <= 80 -----------
   template <class T>
   bool ata_fused_fits(const Big<T>& a, int64_t l) const {
-    (void)l;
-    return std::is_same<T, float>::value && a.cols <= 512 && a.cols >= 16 && a.rows >= 64 * (int64_t)kAtaMinRowsPerGroup;
+    return std::is_same<T, float>::value && a.cols <= 512 && a.cols >= 16 && l <= 80 && a.rows >= 4096;
+  }
+  template <int NK>
+  void ata_launch_nct(int nct, dim3 grid, const k::AtaArgs& g) {
+    const dim3 block(256);
+    switch (nct) {
+      case 1: hipLaunchKernelGGL((k::ata_fused_kernel<NK, 1>), grid, block, k::ata_lds_bytes(NK, 1), stream, g); break;
+      case 2: hipLaunchKernelGGL((k::ata_fused_kernel<NK, 2>), grid, block, k::ata_lds_bytes(NK, 2), stream, g); break;
+      case 3: hipLaunchKernelGGL((k::ata_fused_kernel<NK, 3>), grid, block, k::ata_lds_bytes(NK, 3), stream, g); break;
+      case 4: hipLaunchKernelGGL((k::ata_fused_kernel<NK, 4>), grid, block, k::ata_lds_bytes(NK, 4), stream, g); break;
+      default: hipLaunchKernelGGL((k::ata_fused_kernel<NK, 5>), grid, block, k::ata_lds_bytes(NK, 5), stream, g); break;
+    }
+  }
+  template <int NK>
+  void ata_set_attrs() {
+    const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<NK, 1>, attr, k::ata_lds_bytes(NK, 1)));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<NK, 2>, attr, k::ata_lds_bytes(NK, 2)));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<NK, 3>, attr, k::ata_lds_bytes(NK, 3)));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<NK, 4>, attr, k::ata_lds_bytes(NK, 4)));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::ata_fused_kernel<NK, 5>, attr, k::ata_lds_bytes(NK, 5)));
   }
   template <class T>
   void ata_fused(const Big<T>& a, const Skinny<T>& x, Skinny<T>& z) {
@@ -321,16 +335,15 @@ class HipDev {
     } else {
       if (x.rows != a.cols || z.rows != a.cols) throw Error(ST_EINVAL, "ata_fused: shapes");
       const ColBlocking cb = col_blocking(x.cols);
-      if (cb.cols_alloc > x.cols_alloc || cb.cols_alloc > z.cols_alloc || x.ld != z.ld)
-        throw Error(ST_EINVAL, "internal: ata_fused operands must share the padded layout");
+      if (cb.cols_alloc > x.cols_alloc || cb.cols_alloc > z.cols_alloc || x.ld != z.ld || cb.cols_alloc > 80)
+        throw Error(ST_EINVAL, "internal: ata_fused operands must share the padded layout (<= 80 columns)");
       if (((uintptr_t)a.p % 16) || (a.ld % 4) || (a.cols_readable % 4)) throw Error(ST_EINVAL, "internal: operand not vector aligned");
-      const int nk = (int)((a.cols + 63) / 64);
-      if (x.ld < 64 * nk) throw Error(ST_EINVAL, "internal: skinny leading dimension too small");
+      // reduction segments: n padded to 128 / 256 / 512 (three instantiation families)
+      const int nk = a.cols <= 128 ? 2 : (a.cols <= 256 ? 4 : 8);
       const int nct = (int)(cb.cols_alloc / 16);
-      // one workgroup per CU, row groups in multiples of 8 (the XCD count): ~all CUs busy in one wave of workgroups
-      int nrg = 8 * std::max(1, num_cus / (8 * nct));
+      // one workgroup per CU; every workgroup gets at least a few tiles
       const int64_t blocks = (a.rows + k::kAtaRows - 1) / k::kAtaRows;
-      if ((int64_t)nrg > blocks) nrg = (int)std::max<int64_t>(8, (blocks / 8) * 8);
+      const int nrg = (int)std::max<int64_t>(1, std::min<int64_t>(num_cus, blocks / 8));
       const int64_t rows_per_group = ((blocks + nrg - 1) / nrg) * k::kAtaRows;
       k::AtaArgs g;
       g.a = a.p;
@@ -342,22 +355,14 @@ class HipDev {
       g.z_ld = x.ld;
       g.out_ld = z.ld;
       g.slab_stride = (int64_t)z.ld * cb.cols_alloc;
-      g.slab = (float*)alloc_zeroed((size_t)nrg * (size_t)g.slab_stride * sizeof(float));
+      g.slab = (float*)alloc_zeroed((size_t)nrg * (size_t)g.slab_stride * sizeof(float));  // empty groups contribute zeros
       g.rows_per_group = rows_per_group;
       g.nrowgroups = nrg;
-      g.nct = nct;
       g.zero = (const float*)zero_page_;
-      const dim3 grid((unsigned)(nrg * nct)), block(512);
-      switch (nk) {
-        case 1: hipLaunchKernelGGL((k::ata_fused_kernel<1>), grid, block, k::ata_lds_bytes(1), stream, g); break;
-        case 2: hipLaunchKernelGGL((k::ata_fused_kernel<2>), grid, block, k::ata_lds_bytes(2), stream, g); break;
-        case 3: hipLaunchKernelGGL((k::ata_fused_kernel<3>), grid, block, k::ata_lds_bytes(3), stream, g); break;
-        case 4: hipLaunchKernelGGL((k::ata_fused_kernel<4>), grid, block, k::ata_lds_bytes(4), stream, g); break;
-        case 5: hipLaunchKernelGGL((k::ata_fused_kernel<5>), grid, block, k::ata_lds_bytes(5), stream, g); break;
-        case 6: hipLaunchKernelGGL((k::ata_fused_kernel<6>), grid, block, k::ata_lds_bytes(6), stream, g); break;
-        case 7: hipLaunchKernelGGL((k::ata_fused_kernel<7>), grid, block, k::ata_lds_bytes(7), stream, g); break;
-        default: hipLaunchKernelGGL((k::ata_fused_kernel<8>), grid, block, k::ata_lds_bytes(8), stream, g); break;
-      }
+      const dim3 grid((unsigned)nrg);
+      if (nk == 2) ata_launch_nct<2>(nct, grid, g);
+      else if (nk == 4) ata_launch_nct<4>(nct, grid, g);
+      else ata_launch_nct<8>(nct, grid, g);
       CORRLA_HIP(hipGetLastError());
       dim3 rgd((unsigned)((a.cols + 63) / 64), (unsigned)cb.cols_alloc);
       check_grid(rgd);
@@ -366,7 +371,6 @@ class HipDev {
       CORRLA_HIP(hipGetLastError());
     }
   }
-  static constexpr int kAtaMinRowsPerGroup = 64;
 
   // ---- collectives (RCCL over xGMI, on the compute stream) ---------------------------------
   template <class T>
@@ -1145,6 +1149,8 @@ class HipDev {
   uint64_t entropy_ = 0, calls_ = 0, calls_sharded_ = 0;
   bool no_device_chol_ = false;
   int jmc_min_l_ = 96, jmc_max_b_ = 24;
+  int persist_max_tiles_ = 16;
+  int64_t tall_min_rows_ = 65536;
 
   static void check_grid(const dim3& g) {
     if (g.y > 65535u || g.z > 65535u) throw Error(ST_EINVAL, "problem too large for the launch grid");
@@ -1212,7 +1218,8 @@ class HipDev {
     // the kernels only touch ring buffers [0, min(tiles per workgroup, stages)): a short reduction (the l-deep
     // products Y * R^-1 and U = Q * U~ have 2-3 tiles) asks for less LDS, so several workgroups share a CU and one's
     // load latency hides behind another's MFMAs and stores
-    const int lds = std::min(k::gemm_stages(MW, NT), std::max(1, a.tiles_per_split)) * k::stage_bytes(MW, NT);
+    const int64_t per_wg = (int64_t)std::max(1, a.tiles_per_split) * ((a.outer_blocks + (int64_t)grid.x - 1) / grid.x);
+    const int lds = (int)std::min<int64_t>(k::gemm_stages(MW, NT), per_wg) * k::stage_bytes(MW, NT);
     const dim3 block(64 * (4 + k::kLoaders));  // 4 MFMA waves + loader wave(s)
     if (tn)
       hipLaunchKernelGGL((k::gemm_tn_kernel<T, MW, NT>), grid, block, lds, stream, a);
@@ -1247,6 +1254,96 @@ class HipDev {
       launch_one<T, 1, NT>(tn, grid, a);
   }
 
+  // ---- tall_kernels.hpp: Y M and Y^T Y of a very tall f32 sketch with l <= 96 ----
+  template <int K>
+  void launch_tall_apply(dim3 grid, const k::TallApplyArgs& g) {
+    hipLaunchKernelGGL((k::tall_apply_kernel<K, K>), grid, dim3(256), 0, stream, g);
+  }
+  template <int NCT>
+  void launch_tall_gram(dim3 grid, const k::TallGramArgs& g) {
+    static bool attr_set = false;  // per instantiation; contexts are created under a process-wide lock
+    if (!attr_set) {
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::tall_gram_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     k::gram_lds_bytes(NCT)));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((k::tall_gram_kernel<NCT>), grid, dim3(256), k::gram_lds_bytes(NCT), stream, g);
+  }
+  bool launch_tall(bool tn, const Big<float>& r, const Skinny<float>& x, Skinny<float>& out, const float* scale_dev,
+                   int64_t outer_n, int64_t red_n, const ColBlocking& cb) {
+    if (tall_min_rows_ <= 0) return false;
+    if (tn) {
+      // out (m x n2) = R^T X with R = Y^T stored row-major kdim x m: the columns of Y are contiguous
+      const int64_t m = outer_n, kdim = red_n, n2 = x.cols;
+      if (kdim > 96 || n2 > 96 || m < tall_min_rows_ || r.rows != kdim) return false;
+      if (r.ld < round_up(m, 64) || (r.ld % 4) || ((uintptr_t)r.p % 16)) return false;
+      if (x.external || x.ld < kdim) return false;
+      if (out.rows != m || out.ld < m || out.cols < n2) throw Error(ST_EINVAL, "internal: gemm output shape mismatch");
+      const int kt = (int)std::max((kdim + 15) / 16, (n2 + 15) / 16);
+      k::TallApplyArgs g;
+      g.y = r.p;
+      g.m = m;
+      g.ld_y = r.ld;
+      g.kdim = (int)kdim;
+      g.mat = x.p;
+      g.ld_m = x.ld;
+      g.n2 = (int)n2;
+      g.out = out.p;
+      g.ld_o = out.ld;
+      g.out_cols = (int)(out.external ? out.cols : std::min<int64_t>(out.cols_alloc, 16 * kt));
+      g.scale = scale_dev;
+      g.vec_store = ((out.ld % 4) == 0 && ((uintptr_t)out.p % 16) == 0) ? 1 : 0;
+      const int64_t nblocks = (m + 63) / 64;
+      dim3 grid((unsigned)std::min<int64_t>((nblocks + 3) / 4, num_cus));
+      switch (kt) {
+        case 1: launch_tall_apply<1>(grid, g); break;
+        case 2: launch_tall_apply<2>(grid, g); break;
+        case 3: launch_tall_apply<3>(grid, g); break;
+        case 4: launch_tall_apply<4>(grid, g); break;
+        case 5: launch_tall_apply<5>(grid, g); break;
+        default: launch_tall_apply<6>(grid, g); break;
+      }
+      CORRLA_HIP(hipGetLastError());
+      return true;
+    }
+    // G (l x l) = Y^T Y: both operands are the same column-major m x l memory
+    const int64_t l = outer_n, m = red_n;
+    if ((const void*)r.p != (const void*)x.p || r.ld != x.ld || l != x.cols || l > 96 || m < tall_min_rows_) return false;
+    if ((r.ld % 4) || ((uintptr_t)r.p % 16) || x.external || out.external) return false;
+    const int nct = (int)((l + 15) / 16);
+    if (out.ld < 16 * nct || out.cols_alloc < 16 * nct || cb.cols_alloc < 16 * nct) return false;
+    if (out.rows != l) throw Error(ST_EINVAL, "internal: gemm output shape mismatch");
+    const int64_t rows = x.ld;  // the padding rows are zero and may be read
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(num_cus, rows / (4 * k::kGramRows)));
+    const int64_t rpg = round_up((rows + want - 1) / want, k::kGramRows);
+    const int64_t ngroups = (rows + rpg - 1) / rpg;
+    k::TallGramArgs g;
+    g.y = x.p;
+    g.m = m;
+    g.ld = x.ld;
+    g.l = (int)l;
+    g.slab_stride = (int64_t)out.ld * out.cols_alloc;
+    g.slab = (float*)alloc_bytes((size_t)ngroups * (size_t)g.slab_stride * sizeof(float));
+    g.out_ld = out.ld;
+    g.rows_per_group = rpg;
+    g.zero = (const float*)zero_page_;
+    dim3 grid((unsigned)ngroups);
+    switch (nct) {
+      case 1: launch_tall_gram<1>(grid, g); break;
+      case 2: launch_tall_gram<2>(grid, g); break;
+      case 3: launch_tall_gram<3>(grid, g); break;
+      case 4: launch_tall_gram<4>(grid, g); break;
+      case 5: launch_tall_gram<5>(grid, g); break;
+      default: launch_tall_gram<6>(grid, g); break;
+    }
+    CORRLA_HIP(hipGetLastError());
+    dim3 rg((unsigned)((l + 63) / 64), (unsigned)(16 * nct));
+    hipLaunchKernelGGL((k::slab_reduce_deep_kernel<float>), rg, dim3(256), 0, stream, (const float*)g.slab, g.slab_stride,
+                       (int)ngroups, out.p, out.ld, l, (int64_t)(16 * nct), scale_dev);
+    CORRLA_HIP(hipGetLastError());
+    return true;
+  }
+
   // out (outer_n x L) = scale * op(R) * X; `outer_n` = surviving dimension of R, `red_n` = reduced one
   template <class T>
   void launch_gemm(bool tn, const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale_dev, int64_t outer_n,
@@ -1260,6 +1357,9 @@ class HipDev {
     if (out.rows != outer_n || out.ld < outer_n) throw Error(ST_EINVAL, "internal: gemm output shape mismatch");
     if (((uintptr_t)r.p % 16) || (r.ld % VEC) || (r.cols_readable % VEC) || ((uintptr_t)x.p % 16))
       throw Error(ST_EINVAL, "internal: operand not 16-byte vector aligned");
+    if constexpr (std::is_same<T, float>::value) {
+      if (launch_tall(tn, r, x, out, scale_dev, outer_n, red_n, cb)) return;
+    }
     const int64_t tiles64 = (red_n + KT - 1) / KT;
     if (tiles64 > 0x7fffffff) throw Error(ST_EINVAL, "reduction dimension too large");
     const int tiles_total = (int)tiles64;
@@ -1308,15 +1408,28 @@ class HipDev {
     a.slab = nullptr;
     a.slab_stride = (int64_t)out.ld * cb.cols_alloc;
     if (nsplit > 1) a.slab = (T*)alloc_bytes((size_t)nsplit * (size_t)a.slab_stride * sizeof(T));
-    dim3 grid((unsigned)outer_tiles, (unsigned)cb.nblk, (unsigned)nsplit);
+    a.outer_blocks = (int)outer_tiles;
+    a.vec_store = ((out.ld % 4) == 0 && ((uintptr_t)out.p % 16) == 0) ? 1 : 0;
+    a.rotate = (!tn && !alias && a.tiles_per_split <= 32 && a.tiles_per_split > 1 && !env_int("CORRLA_GEMM_NO_ROTATE", 0)) ? 1 : 0;
+    // Short reductions (A Z with n = 512: 8 tiles; Y R^-1: 2): a workgroup per outer tile spends a fifth of its life
+    // waiting for its first tile.  A persistent launch -- as many workgroups as fit the chip at once, each walking its
+    // outer tiles with the DMA ring running on across the boundaries -- pays that latency once.
+    int64_t gx = outer_tiles;
+    if (!alias && a.tiles_per_split <= persist_max_tiles_) {
+      const int64_t lds_full = (int64_t)k::gemm_stages(mw, cb.nt) * k::stage_bytes(mw, cb.nt);
+      const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(4, (160 * 1024) / lds_full));
+      const int64_t slots = per_cu * num_cus / ((int64_t)cb.nblk * nsplit);
+      if (slots >= 1 && outer_tiles >= 3 * slots) gx = slots;
+    }
+    dim3 grid((unsigned)gx, (unsigned)cb.nblk, (unsigned)nsplit);
     check_grid(grid);
     a.col_base = 0;
     // Uneven column blocking: `tiles` 16-column tiles over nblk blocks need not all be cb.nt wide -- 17 tiles (l = 266)
     // are 9 + 8, not 9 + 9: the narrower blocks run the next-smaller instantiation in a second launch and skip the
     // all-zero padding tile (5.5 % of the MFMA work of every tall product at l = 266).
     if (uneven) {
-      dim3 g1((unsigned)outer_tiles, (unsigned)n_wide, (unsigned)nsplit);
-      dim3 g2((unsigned)outer_tiles, (unsigned)(cb.nblk - n_wide), (unsigned)nsplit);
+      dim3 g1((unsigned)gx, (unsigned)n_wide, (unsigned)nsplit);
+      dim3 g2((unsigned)gx, (unsigned)(cb.nblk - n_wide), (unsigned)nsplit);
       launch_nt<T>(tn, mw, cb.nt, g1, a);
       a.col_base = (int64_t)n_wide * cb.nt * 16;
       launch_nt<T>(tn, mw, cb.nt - 1, g2, a);

@@ -42,6 +42,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CORRLA_F32_BIG_IS_A
+#define CORRLA_F32_BIG_IS_A true  // see MT<float>::kBigIsA
+#endif
 template <class T>
 struct MT;
 template <>
@@ -50,6 +53,10 @@ struct MT<float> {
   typedef f32x4 vec_t;
   static constexpr int VEC = 4;  // elements per 16 bytes
   static constexpr int KT = 64;  // reduction elements per 256-byte LDS row
+  // The tall GEMMs feed the BIG operand as MFMA A and the skinny one as B: a lane's four D registers are then four
+  // consecutive OUTER indices of one result column, i.e. one 16-byte store (a quarter of the store instructions of
+  // the other order; 10^7 x 80 results made the stores 10 % of the product's time).
+  static constexpr bool kBigIsA = CORRLA_F32_BIG_IS_A;
   static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
@@ -65,6 +72,8 @@ struct MT<double> {
   typedef f64x2 vec_t;
   static constexpr int VEC = 2;
   static constexpr int KT = 32;
+  // f64 D registers are 4 rows apart: the skinny operand stays MFMA A, so that 16 lanes store 128 contiguous bytes
+  static constexpr bool kBigIsA = false;
   static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
@@ -120,6 +129,11 @@ struct GemmArgs {
   int tiles_per_split;
   int nsplit;
   int debug_flags;    // timing-only ablation (wrong results): 1 = no DMA after the first tile
+  int vec_store;      // out (and the slabs) are 16-byte aligned with out_ld % 4 == 0
+  int rotate;         // gemm_nn: workgroup x walks the reduction tiles from tile x mod (tiles per split), wrapping
+  int outer_blocks;   // outer tiles in all; workgroup x of gridDim.x takes x, x + gridDim.x, ... (persistent launches of
+                      // short reductions: the DMA ring runs on across the tile boundary, so only the first outer tile
+                      // of a workgroup pays the fill latency)
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -193,11 +207,19 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
 }
 
+// skinny-operand element x, big-operand element r of one k index -> acc (see MT<T>::kBigIsA)
+template <class T>
+__device__ __forceinline__ typename MT<T>::acc_t gemm_mma(T x, T r, typename MT<T>::acc_t c) {
+  if constexpr (MT<T>::kBigIsA)
+    return MT<T>::mma(r, x, c);
+  else
+    return MT<T>::mma(x, r, c);
+}
+
 template <class T, int NT>
 __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename MT<T>::acc_t (&acc)[NT], int64_t outer0,
                                            int64_t outer_limit, int64_t col0, int lane) {
-  const int64_t outer = outer0 + (lane & 15);
-  if (outer >= outer_limit) return;
+  if (g.debug_flags & 8) return;  // timing-only ablation: no result stores
   T* dst;
   T sc = (T)1;
   if (g.nsplit > 1) {
@@ -206,12 +228,35 @@ __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename 
     dst = g.out;
     if (g.scale) sc = *g.scale;
   }
+  if constexpr (MT<T>::kBigIsA) {
+    // D: column = lane & 15 (result column), rows 4 (lane >> 4) + j (outer indices)
+    const int64_t outer = outer0 + 4 * (lane >> 4);
+    if (outer >= outer_limit) return;
+    const bool whole = g.vec_store && outer + 3 < outer_limit;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NT; ++t) {
+      const int64_t col = col0 + 16 * t + (lane & 15);
+      if (g.nsplit > 1 || col < g.out_cols) {
+        T* p = dst + col * g.out_ld + outer;
+        if (whole) {
+          *(typename MT<T>::acc_t*)p = acc[t] * sc;
+        } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t col = col0 + 16 * t + MT<T>::drow(lane, j);
-      if (g.nsplit > 1 || col < g.out_cols) dst[col * g.out_ld + outer] = acc[t][j] * sc;
+          for (int j = 0; j < 4; ++j)
+            if (outer + j < outer_limit) p[j] = acc[t][j] * sc;
+        }
+      }
+    }
+  } else {
+    const int64_t outer = outer0 + (lane & 15);
+    if (outer >= outer_limit) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = col0 + 16 * t + MT<T>::drow(lane, j);
+        if (g.nsplit > 1 || col < g.out_cols) dst[col * g.out_ld + outer] = acc[t][j] * sc;
+      }
     }
   }
 }
@@ -234,17 +279,14 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row0 = (int64_t)blockIdx.x * outer_tile(MW);
+  const int64_t row_first = (int64_t)blockIdx.x * outer_tile(MW);
   const int64_t col0 = g.col_base + (int64_t)blockIdx.y * (NT * 16);
   const int t_begin = blockIdx.z * g.tiles_per_split;
   const int t_end = min(t_begin + g.tiles_per_split, g.tiles_total);
   const int nk = t_end - t_begin;
-
-  acc_t acc[MW][NT];
-#pragma unroll
-  for (int mw = 0; mw < MW; ++mw)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[mw][t] = (acc_t){0, 0, 0, 0};
+  // outer tiles of this workgroup: blockIdx.x, blockIdx.x + gridDim.x, ... (one when the grid covers them all)
+  const int nob = (g.outer_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int64_t ob_rows = (int64_t)gridDim.x * outer_tile(MW);
 
   // Waves 0..3 are MFMA waves; waves 4.. (kLoaders of them) are LOADER waves that only issue the LDS-DMA of the next tile
   // (a global_load_lds costs its issuing wave ~100 cycles, which an in-order MFMA wave cannot hide: with
@@ -254,6 +296,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
   if (wave >= 4) {
     __builtin_amdgcn_s_setprio(3);  // few instructions, but they gate everyone: win the issue arbitration
     // generic (bounds-checked) issue of one tile: used for edge tiles only
+    int64_t row0 = row_first;  // outer tile being STAGED (runs ahead of the one being multiplied)
     auto stage_checked = [&](int buf, int kt) {
       char* rt = smem + buf * STAGE;
       const int64_t k0 = (int64_t)kt * KT;
@@ -280,22 +323,32 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
     // feed accumulators whose outer index is >= r_rows and is never stored
     DmaStream<NV, ALIAS ? NT : 4 * MW, NL> big;
     DmaStream<NV, NT, NL> sk;
+    // rotated reduction order (g.rotate): workgroup x starts at tile x mod nk and wraps.  With a short row (n = 512:
+    // 2 KB) every workgroup of a launch would otherwise sit on the same 256-byte phase of its rows at the same time,
+    // i.e. on one eighth of the memory channels.
+    const int rot = g.rotate ? (int)(blockIdx.x % (unsigned)nk) : 0;
 #pragma unroll
     for (int pv = 0; pv < NV; ++pv) {
       const int row = 4 * (lw + NL * pv) + (lane >> 4);
       const int ls = (lane & 15) ^ (row & 15);
-      big.ptr[pv] = (const char*)(g.r + (row0 + row) * g.r_ld + (int64_t)t_begin * KT + ls * VEC);
-      sk.ptr[pv] = (const char*)(g.x + (col0 + row) * g.x_ld + (int64_t)t_begin * KT + ls * VEC);
+      big.ptr[pv] = (const char*)(g.r + (row0 + row) * g.r_ld + (int64_t)(t_begin + rot) * KT + ls * VEC);
+      sk.ptr[pv] = (const char*)(g.x + (col0 + row) * g.x_ld + (int64_t)(t_begin + rot) * KT + ls * VEC);
     }
     big.step = 16 * g.r_ld * (int64_t)sizeof(T);
     big.adv = KT * (int64_t)sizeof(T);
     sk.step = 16 * g.x_ld * (int64_t)sizeof(T);
     sk.adv = KT * (int64_t)sizeof(T);
     // alias: the host guarantees 16 * NT allocated columns (x.cols_alloc), all of them readable
-    const bool rows_inside = ALIAS ? true : (row0 + outer_tile(MW) <= g.r_rows);
+    bool rows_inside = ALIAS ? true : (row0 + outer_tile(MW) <= g.r_rows);
     auto stage_tile = [&](int buf, int kt) {
       char* rt = smem + buf * STAGE;
       if (rows_inside && (int64_t)(kt + 1) * KT <= g.r_cols_readable) {
+        if (g.debug_flags & 6) {  // timing-only ablations: 2 = no skinny-operand DMA, 4 = no big-operand DMA
+          if (!(g.debug_flags & 4)) big.issue(rt + lw * 1024);
+          if constexpr (!ALIAS)
+            if (!(g.debug_flags & 2)) sk.issue(rt + BIG + lw * 1024);
+          return;
+        }
         big.issue(rt + lw * 1024);
         if constexpr (!ALIAS) sk.issue(rt + BIG + lw * 1024);
       } else {
@@ -311,19 +364,49 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
     constexpr int NSTAGE = ALIAS ? 3 : gemm_stages(MW, NT);
     static_assert((16 * MW) % kLoaders == 0 && (4 * NT) % kLoaders == 0, "chunks must split evenly over the loaders");
     constexpr int DPL = ALIAS ? NT : (16 * MW + 4 * NT) / kLoaders;  // DMA instructions per loader wave per tile
-    for (int t = 0; t < NSTAGE - 1 && t < nk; ++t) stage_tile(t % NSTAGE, t_begin + t);
-    for (int i = 0; i < nk; ++i) {
+    // the tiles of all outer tiles of this workgroup form ONE sequence through the ring
+    const int nflat = nob * nk;
+    const int64_t wrap = -(int64_t)nk * KT * (int64_t)sizeof(T);  // back to the first tile of the reduction range
+    const int64_t big_jump = ob_rows * g.r_ld * (int64_t)sizeof(T);
+    int s_k = rot, s_n = 0;
+    auto stage_next = [&](int buf) {
+      stage_tile(buf, t_begin + s_k);
+      if (++s_k == nk) {
+        s_k = 0;
+#pragma unroll
+        for (int pv = 0; pv < NV; ++pv) {
+          big.ptr[pv] += wrap;
+          sk.ptr[pv] += wrap;
+        }
+      }
+      if (++s_n == nk) {  // on to the next outer tile (the streams are back at tile `rot`)
+        s_n = 0;
+        row0 += ob_rows;
+#pragma unroll
+        for (int pv = 0; pv < NV; ++pv) big.ptr[pv] += big_jump;
+        if constexpr (!ALIAS) rows_inside = row0 + outer_tile(MW) <= g.r_rows;
+      }
+    };
+    for (int t = 0; t < NSTAGE - 1 && t < nflat; ++t) stage_next(t % NSTAGE);
+    for (int i = 0; i < nflat; ++i) {
       // tile i must have landed; the (NSTAGE-2) younger tiles may stay in flight (vmcnt counts in issue order)
-      if (NSTAGE > 2 && i + NSTAGE - 2 < nk)
-        wait_vmcnt<(NSTAGE - 2) * DPL>();
-      else
+      if (NSTAGE > 2 && i + NSTAGE - 2 < nflat) {
+        if (g.debug_flags & 2)
+          wait_vmcnt<(NSTAGE - 2) * (16 * MW / kLoaders)>();
+        else if (g.debug_flags & 4)
+          wait_vmcnt<(NSTAGE - 2) * (4 * NT / kLoaders)>();
+        else
+          wait_vmcnt<(NSTAGE - 2) * DPL>();
+      } else {
         wait_vmcnt<0>();
+      }
       wg_barrier();  // tile i visible to the MFMA waves; they are done reading buffer (i-1) % NSTAGE
-      if (i + NSTAGE - 1 < nk && !(g.debug_flags & 1)) stage_tile((i + NSTAGE - 1) % NSTAGE, t_begin + i + NSTAGE - 1);
+      if (i + NSTAGE - 1 < nflat && !(g.debug_flags & 1)) stage_next((i + NSTAGE - 1) % NSTAGE);
     }
     return;
   }
 
+  acc_t acc[MW][NT];
   // Fragment read addresses (bytes inside a stage), lane-invariant across tiles: for fragment group
   // gq this lane reads 16-byte slot (4*gq + kq) ^ c of its row in both images.
   const int fc = lane & 15, fkq = lane >> 4;
@@ -353,7 +436,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
 #pragma unroll
     for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(afr[st][j], bfr[gq][mw][j], acc[mw][t]);
+      for (int j = 0; j < VEC; ++j) acc[mw][t] = gemm_mma<T>(afr[st][j], bfr[gq][mw][j], acc[mw][t]);
   };
   auto compute = [&](int buf, bool have_prev) {
     const unsigned sb = (unsigned)(buf * STAGE);
@@ -387,7 +470,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
 #pragma unroll
           for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(da[d][j], db[mw][j], acc[mw][t]);
+            for (int j = 0; j < VEC; ++j) acc[mw][t] = gemm_mma<T>(da[d][j], db[mw][j], acc[mw][t]);
         });
       }
     }
@@ -407,16 +490,26 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
     });
   };
 
-  for (int i = 0; i < nk; ++i) {
-    wg_barrier();  // matches the loaders' barrier: tile i is in LDS (all of this wave's LDS reads are retired)
-    compute(i % (ALIAS ? 3 : gemm_stages(MW, NT)), i > 0);
-  }
-  if constexpr (kDefer > 0) {
-    if (nk > 0) static_for<NS - kDefer, NS>(mfma_step);
-  }
+  constexpr int NSTAGE_C = ALIAS ? 3 : gemm_stages(MW, NT);
+  int buf = 0;
+  int64_t row0 = row_first;
+  for (int ob = 0; ob < nob; ++ob, row0 += ob_rows) {
 #pragma unroll
-  for (int mw = 0; mw < MW; ++mw)
-    store_tile<T, NT>(g, acc[mw], row0 + 16 * MW * wave + 16 * mw, g.r_rows, col0, lane);
+    for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[mw][t] = (acc_t){0, 0, 0, 0};
+    for (int i = 0; i < nk; ++i) {
+      wg_barrier();  // matches the loaders' barrier: tile i is in LDS (all of this wave's LDS reads are retired)
+      compute(buf, i > 0);
+      buf = buf + 1 == NSTAGE_C ? 0 : buf + 1;
+    }
+    if constexpr (kDefer > 0) {
+      if (nk > 0) static_for<NS - kDefer, NS>(mfma_step);
+    }
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw)
+      store_tile<T, NT>(g, acc[mw], row0 + 16 * MW * wave + 16 * mw, g.r_rows, col0, lane);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -435,23 +528,21 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t n0 = (int64_t)blockIdx.x * outer_tile(MW);
+  const int64_t n_first = (int64_t)blockIdx.x * outer_tile(MW);
   const int64_t col0 = g.col_base + (int64_t)blockIdx.y * (NT * 16);
   const int t_begin = blockIdx.z * g.tiles_per_split;
   const int t_end = min(t_begin + g.tiles_per_split, g.tiles_total);
   const int nk = t_end - t_begin;
-
-  acc_t acc[MW][NT];
-#pragma unroll
-  for (int mw = 0; mw < MW; ++mw)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[mw][t] = (acc_t){0, 0, 0, 0};
+  // outer tiles of this workgroup: blockIdx.x, blockIdx.x + gridDim.x, ... (see gemm_nn_kernel)
+  const int nob = (g.outer_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int64_t ob_cols = (int64_t)gridDim.x * outer_tile(MW);
 
   // The loader wave (4) issues the LDS-DMA, waves 0..3 run the MFMAs (see gemm_nn).  The big tile is a
   // row-linear LDS image of KT reduction rows x (64*MW outer columns); 16-byte slot lin = 64c + lane of
   // chunk c holds logical slot (lin % LPR) ^ tswz(row) of row lin / LPR.
   if (wave >= 4) {
     __builtin_amdgcn_s_setprio(3);
+    int64_t n0 = n_first;  // outer tile being STAGED
     auto stage_checked = [&](int buf, int mt) {
       char* rt = smem + buf * STAGE;
       const int64_t m0 = (int64_t)mt * KT;
@@ -493,7 +584,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
     big.adv = (int64_t)KT * g.r_ld * (int64_t)sizeof(T);
     sk.step = 16 * g.x_ld * (int64_t)sizeof(T);
     sk.adv = KT * (int64_t)sizeof(T);
-    const bool cols_inside = n0 + outer_tile(MW) <= g.r_cols_readable;
+    bool cols_inside = n0 + outer_tile(MW) <= g.r_cols_readable;
     auto stage_tile = [&](int buf, int mt) {
       char* rt = smem + buf * STAGE;
       if (cols_inside && (int64_t)(mt + 1) * KT <= g.r_rows) {
@@ -511,18 +602,35 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
     constexpr int NSTAGE = gemm_stages(MW, NT);
     static_assert((16 * MW) % kLoaders == 0 && (4 * NT) % kLoaders == 0, "chunks must split evenly over the loaders");
     constexpr int DPL = (16 * MW + 4 * NT) / kLoaders;  // DMA instructions per loader wave per tile
-    for (int t = 0; t < NSTAGE - 1 && t < nk; ++t) stage_tile(t % NSTAGE, t_begin + t);
-    for (int i = 0; i < nk; ++i) {
+    const int nflat = nob * nk;
+    const int64_t big_jump = (ob_cols - (int64_t)nk * KT * g.r_ld) * (int64_t)sizeof(T);
+    const int64_t sk_jump = -(int64_t)nk * KT * (int64_t)sizeof(T);
+    int s_k = 0;
+    auto stage_next = [&](int buf) {
+      stage_tile(buf, t_begin + s_k);
+      if (++s_k == nk) {  // on to the next outer tile
+        s_k = 0;
+        n0 += ob_cols;
+#pragma unroll
+        for (int pv = 0; pv < NVB; ++pv) big.ptr[pv] += big_jump;
+#pragma unroll
+        for (int pv = 0; pv < NV; ++pv) sk.ptr[pv] += sk_jump;
+        cols_inside = n0 + outer_tile(MW) <= g.r_cols_readable;
+      }
+    };
+    for (int t = 0; t < NSTAGE - 1 && t < nflat; ++t) stage_next(t % NSTAGE);
+    for (int i = 0; i < nflat; ++i) {
       // tile i must have landed; the (NSTAGE-2) younger tiles may stay in flight (vmcnt counts in issue order)
-      if (NSTAGE > 2 && i + NSTAGE - 2 < nk)
+      if (NSTAGE > 2 && i + NSTAGE - 2 < nflat)
         wait_vmcnt<(NSTAGE - 2) * DPL>();
       else
         wait_vmcnt<0>();
       wg_barrier();  // tile i visible to the MFMA waves; they are done reading buffer (i-1) % NSTAGE
-      if (i + NSTAGE - 1 < nk && !(g.debug_flags & 1)) stage_tile((i + NSTAGE - 1) % NSTAGE, t_begin + i + NSTAGE - 1);
+      if (i + NSTAGE - 1 < nflat && !(g.debug_flags & 1)) stage_next((i + NSTAGE - 1) % NSTAGE);
     }
     return;
   }
+  acc_t acc[MW][NT];
 
   // Fragment read addresses (bytes inside a stage), lane-invariant across tiles.  Skinny image: as in
   // gemm_nn.  Big image: element (reduction row mloc, outer column ncol) sits at
@@ -552,7 +660,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
 #pragma unroll
     for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(afr[st][j], bfr[gq][mw][j], acc[mw][t]);
+      for (int j = 0; j < VEC; ++j) acc[mw][t] = gemm_mma<T>(afr[st][j], bfr[gq][mw][j], acc[mw][t]);
   };
   auto compute = [&](int buf, bool have_prev) {
     const unsigned sb = (unsigned)(buf * STAGE);
@@ -587,7 +695,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
 #pragma unroll
           for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) acc[mw][t] = MT<T>::mma(da[d][j], db[mw][j], acc[mw][t]);
+            for (int j = 0; j < VEC; ++j) acc[mw][t] = gemm_mma<T>(da[d][j], db[mw][j], acc[mw][t]);
         });
       }
     }
@@ -606,16 +714,25 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
     });
   };
 
-  for (int i = 0; i < nk; ++i) {
-    wg_barrier();
-    compute(i % gemm_stages(MW, NT), i > 0);
-  }
-  if constexpr (kDefer > 0) {
-    if (nk > 0) static_for<NS - kDefer, NS>(mfma_step);
-  }
+  int buf = 0;
+  int64_t n0 = n_first;
+  for (int ob = 0; ob < nob; ++ob, n0 += ob_cols) {
 #pragma unroll
-  for (int mw = 0; mw < MW; ++mw)
-    store_tile<T, NT>(g, acc[mw], n0 + 16 * MW * wave + 16 * mw, g.r_cols, col0, lane);
+    for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[mw][t] = (acc_t){0, 0, 0, 0};
+    for (int i = 0; i < nk; ++i) {
+      wg_barrier();
+      compute(buf, i > 0);
+      buf = buf + 1 == gemm_stages(MW, NT) ? 0 : buf + 1;
+    }
+    if constexpr (kDefer > 0) {
+      if (nk > 0) static_for<NS - kDefer, NS>(mfma_step);
+    }
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw)
+      store_tile<T, NT>(g, acc[mw], n0 + 16 * MW * wave + 16 * mw, g.r_cols, col0, lane);
+  }
 }
 
 // out[col][i] = scale * sum_z slab[z][col][i], i < limit, col < ncols; fixed summation tree (deterministic)

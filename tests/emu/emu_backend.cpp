@@ -146,8 +146,8 @@ class EmuDev {
   }
   // same contract as HipDev::ata_fused: z = A^T (A x), the intermediate rounded to T like the kernel's f32 T tile
   template <class T>
-  bool ata_fused_fits(const Big<T>& a, int64_t) const {
-    return sizeof(T) == 4 && a.cols <= 512 && a.cols >= 16 && a.rows >= 64 * 64;
+  bool ata_fused_fits(const Big<T>& a, int64_t l) const {
+    return sizeof(T) == 4 && a.cols <= 512 && a.cols >= 16 && l <= 80 && a.rows >= 4096;
   }
   template <class T>
   void ata_fused(const Big<T>& a, const Skinny<T>& x, Skinny<T>& z) {

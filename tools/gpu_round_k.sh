@@ -1,0 +1,8 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r02
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "one_sweep" > gpurun_out/r02/pytest11_fused.log 2>&1
+rc=$?; echo "pytest fused rc=$rc" | tee -a gpurun_out/r02/pytest11_fused.log
+tail -12 gpurun_out/r02/pytest11_fused.log
+[ $rc -eq 0 ] && timeout -k 10 300 python tools/bench_configs.py C4shard 2>/dev/null | tee gpurun_out/r02/f4v2b_unfused.json && \
+FUSED=1 timeout -k 10 300 python tools/bench_configs.py C4shard 2>/dev/null | tee gpurun_out/r02/f4v2b_fused.json
