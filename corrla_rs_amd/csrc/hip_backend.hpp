@@ -1254,33 +1254,36 @@ class HipDev {
       launch_one<T, 1, NT>(tn, grid, a);
   }
 
-  // ---- tall_kernels.hpp: Y M and Y^T Y of a very tall f32 sketch with l <= 96 ----
-  template <int K>
-  void launch_tall_apply(dim3 grid, const k::TallApplyArgs& g) {
-    hipLaunchKernelGGL((k::tall_apply_kernel<K, K>), grid, dim3(256), 0, stream, g);
+  // ---- tall_kernels.hpp: Y M and Y^T Y of a very tall sketch with l <= 96 (f32) / 64 (f64) ----
+  template <class T, int K>
+  void launch_tall_apply(dim3 grid, const k::TallApplyArgs<T>& g) {
+    hipLaunchKernelGGL((k::tall_apply_kernel<T, K, K>), grid, dim3(256), 0, stream, g);
   }
-  template <int NCT>
-  void launch_tall_gram(dim3 grid, const k::TallGramArgs& g) {
+  template <class T, int NCT>
+  void launch_tall_gram(dim3 grid, const k::TallGramArgs<T>& g) {
     static bool attr_set = false;  // per instantiation; contexts are created under a process-wide lock
+    const int lds = k::gram_lds_bytes(NCT, (int)sizeof(T));
     if (!attr_set) {
-      CORRLA_HIP(hipFuncSetAttribute((const void*)k::tall_gram_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     k::gram_lds_bytes(NCT)));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::tall_gram_kernel<T, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       attr_set = true;
     }
-    hipLaunchKernelGGL((k::tall_gram_kernel<NCT>), grid, dim3(256), k::gram_lds_bytes(NCT), stream, g);
+    hipLaunchKernelGGL((k::tall_gram_kernel<T, NCT>), grid, dim3(256), lds, stream, g);
   }
-  bool launch_tall(bool tn, const Big<float>& r, const Skinny<float>& x, Skinny<float>& out, const float* scale_dev,
-                   int64_t outer_n, int64_t red_n, const ColBlocking& cb) {
+  template <class T>
+  bool launch_tall(bool tn, const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale_dev, int64_t outer_n,
+                   int64_t red_n, const ColBlocking& cb) {
+    constexpr int kMaxL = sizeof(T) == 4 ? 96 : 64;  // register budget of the B fragments
+    constexpr int kVecElems = 16 / (int)sizeof(T);
     if (tall_min_rows_ <= 0) return false;
     if (tn) {
       // out (m x n2) = R^T X with R = Y^T stored row-major kdim x m: the columns of Y are contiguous
       const int64_t m = outer_n, kdim = red_n, n2 = x.cols;
-      if (kdim > 96 || n2 > 96 || m < tall_min_rows_ || r.rows != kdim) return false;
-      if (r.ld < round_up(m, 64) || (r.ld % 4) || ((uintptr_t)r.p % 16)) return false;
+      if (kdim > kMaxL || n2 > kMaxL || m < tall_min_rows_ || r.rows != kdim) return false;
+      if (r.ld < round_up(m, 64) || (r.ld % kVecElems) || ((uintptr_t)r.p % 16)) return false;
       if (x.external || x.ld < kdim) return false;
       if (out.rows != m || out.ld < m || out.cols < n2) throw Error(ST_EINVAL, "internal: gemm output shape mismatch");
       const int kt = (int)std::max((kdim + 15) / 16, (n2 + 15) / 16);
-      k::TallApplyArgs g;
+      k::TallApplyArgs<T> g;
       g.y = r.p;
       g.m = m;
       g.ld_y = r.ld;
@@ -1292,54 +1295,67 @@ class HipDev {
       g.ld_o = out.ld;
       g.out_cols = (int)(out.external ? out.cols : std::min<int64_t>(out.cols_alloc, 16 * kt));
       g.scale = scale_dev;
-      g.vec_store = ((out.ld % 4) == 0 && ((uintptr_t)out.p % 16) == 0) ? 1 : 0;
-      const int64_t nblocks = (m + 63) / 64;
+      g.vec_store = ((out.ld % kVecElems) == 0 && ((uintptr_t)out.p % 16) == 0) ? 1 : 0;
+      const int64_t nblocks = (m + 16 * kVecElems - 1) / (16 * kVecElems);
       dim3 grid((unsigned)std::min<int64_t>((nblocks + 3) / 4, num_cus));
       switch (kt) {
-        case 1: launch_tall_apply<1>(grid, g); break;
-        case 2: launch_tall_apply<2>(grid, g); break;
-        case 3: launch_tall_apply<3>(grid, g); break;
-        case 4: launch_tall_apply<4>(grid, g); break;
-        case 5: launch_tall_apply<5>(grid, g); break;
-        default: launch_tall_apply<6>(grid, g); break;
+        case 1: launch_tall_apply<T, 1>(grid, g); break;
+        case 2: launch_tall_apply<T, 2>(grid, g); break;
+        case 3: launch_tall_apply<T, 3>(grid, g); break;
+        case 4: launch_tall_apply<T, 4>(grid, g); break;
+        default:
+          if constexpr (sizeof(T) == 4) {
+            if (kt == 5)
+              launch_tall_apply<T, 5>(grid, g);
+            else
+              launch_tall_apply<T, 6>(grid, g);
+          }
+          break;
       }
       CORRLA_HIP(hipGetLastError());
       return true;
     }
     // G (l x l) = Y^T Y: both operands are the same column-major m x l memory
     const int64_t l = outer_n, m = red_n;
-    if ((const void*)r.p != (const void*)x.p || r.ld != x.ld || l != x.cols || l > 96 || m < tall_min_rows_) return false;
-    if ((r.ld % 4) || ((uintptr_t)r.p % 16) || x.external || out.external) return false;
+    if ((const void*)r.p != (const void*)x.p || r.ld != x.ld || l != x.cols || l > kMaxL || m < tall_min_rows_) return false;
+    if ((r.ld % kVecElems) || ((uintptr_t)r.p % 16) || x.external || out.external) return false;
     const int nct = (int)((l + 15) / 16);
     if (out.ld < 16 * nct || out.cols_alloc < 16 * nct || cb.cols_alloc < 16 * nct) return false;
     if (out.rows != l) throw Error(ST_EINVAL, "internal: gemm output shape mismatch");
+    constexpr int kRows = k::gram_rows<T>();
     const int64_t rows = x.ld;  // the padding rows are zero and may be read
-    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(num_cus, rows / (4 * k::kGramRows)));
-    const int64_t rpg = round_up((rows + want - 1) / want, k::kGramRows);
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(num_cus, rows / (4 * kRows)));
+    const int64_t rpg = round_up((rows + want - 1) / want, kRows);
     const int64_t ngroups = (rows + rpg - 1) / rpg;
-    k::TallGramArgs g;
+    k::TallGramArgs<T> g;
     g.y = x.p;
     g.m = m;
     g.ld = x.ld;
     g.l = (int)l;
     g.slab_stride = (int64_t)out.ld * out.cols_alloc;
-    g.slab = (float*)alloc_bytes((size_t)ngroups * (size_t)g.slab_stride * sizeof(float));
+    g.slab = (T*)alloc_bytes((size_t)ngroups * (size_t)g.slab_stride * sizeof(T));
     g.out_ld = out.ld;
     g.rows_per_group = rpg;
-    g.zero = (const float*)zero_page_;
+    g.zero = (const T*)zero_page_;
     dim3 grid((unsigned)ngroups);
     switch (nct) {
-      case 1: launch_tall_gram<1>(grid, g); break;
-      case 2: launch_tall_gram<2>(grid, g); break;
-      case 3: launch_tall_gram<3>(grid, g); break;
-      case 4: launch_tall_gram<4>(grid, g); break;
-      case 5: launch_tall_gram<5>(grid, g); break;
-      default: launch_tall_gram<6>(grid, g); break;
+      case 1: launch_tall_gram<T, 1>(grid, g); break;
+      case 2: launch_tall_gram<T, 2>(grid, g); break;
+      case 3: launch_tall_gram<T, 3>(grid, g); break;
+      case 4: launch_tall_gram<T, 4>(grid, g); break;
+      default:
+        if constexpr (sizeof(T) == 4) {
+          if (nct == 5)
+            launch_tall_gram<T, 5>(grid, g);
+          else
+            launch_tall_gram<T, 6>(grid, g);
+        }
+        break;
     }
     CORRLA_HIP(hipGetLastError());
     dim3 rg((unsigned)((l + 63) / 64), (unsigned)(16 * nct));
-    hipLaunchKernelGGL((k::slab_reduce_deep_kernel<float>), rg, dim3(256), 0, stream, (const float*)g.slab, g.slab_stride,
-                       (int)ngroups, out.p, out.ld, l, (int64_t)(16 * nct), scale_dev);
+    hipLaunchKernelGGL((k::slab_reduce_deep_kernel<T>), rg, dim3(256), 0, stream, (const T*)g.slab, g.slab_stride, (int)ngroups,
+                       out.p, out.ld, l, (int64_t)(16 * nct), scale_dev);
     CORRLA_HIP(hipGetLastError());
     return true;
   }
@@ -1357,9 +1373,7 @@ class HipDev {
     if (out.rows != outer_n || out.ld < outer_n) throw Error(ST_EINVAL, "internal: gemm output shape mismatch");
     if (((uintptr_t)r.p % 16) || (r.ld % VEC) || (r.cols_readable % VEC) || ((uintptr_t)x.p % 16))
       throw Error(ST_EINVAL, "internal: operand not 16-byte vector aligned");
-    if constexpr (std::is_same<T, float>::value) {
-      if (launch_tall(tn, r, x, out, scale_dev, outer_n, red_n, cb)) return;
-    }
+    if (launch_tall<T>(tn, r, x, out, scale_dev, outer_n, red_n, cb)) return;
     const int64_t tiles64 = (red_n + KT - 1) / KT;
     if (tiles64 > 0x7fffffff) throw Error(ST_EINVAL, "reduction dimension too large");
     const int tiles_total = (int)tiles64;
