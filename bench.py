@@ -81,7 +81,7 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
-def pmc_traffic(kernel_substr="gemm_nn_kernel<float, 2, 9>"):
+def pmc_traffic(kernel_substr="gemm_nn_kernel<float, 2, 9"):
     """HBM bytes per launch of the sketch kernel from the newest tracked rocprofv3 PMC summary under profiles/
     (separate --pmc passes, FETCH_SIZE x 2 on gfx950 + WRITE_SIZE: MI355X_MICROARCH.md, HBM section) -- the numbers are
     read from the file, never kept as constants here.  Returns (bytes or None, source)."""
