@@ -606,23 +606,31 @@ class HipDev {
   template <class T>
   void set_jmc_attrs() {
     const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 1>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 2>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 3>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 4>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 5>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 6>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 7>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 8>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 9>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 1, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 2, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 3, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 4, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 5, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 6, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 7, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 8, 16>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::jmc_step_kernel<T, 9, 16>, attr, 160 * 1024));
   }
 
   // ---- multi-workgroup block Jacobi (jacobi_mc_kernels.hpp) ------------------------------------------------
+  // lanes per Jacobi processor.  (8-lane processors -- half the waves for the same block pair, twice the column per
+  // lane -- measured 6 % slower at l = 138 f32: the rounds are bound by the per-lane column traffic, not by the
+  // rotation arithmetic they would amortise; the kernel keeps the template parameter, nothing instantiates 8.)
+  template <class T>
+  int jmc_lanes(int64_t) const {
+    return 16;
+  }
   // geometry for an l x l core: chunk rows NC, workgroups NP, block width b (even, <= 32); false when it does not fit
   template <class T>
   bool jmc_geometry(int64_t l, int* nc_out, int* np_out, int* b_out) const {
     if (l < 2 || l > 288) return false;
-    const int nc = (int)((l + 31) / 32);
+    const int lanes = jmc_lanes<T>(l);
+    const int nc = (int)((l + 2 * lanes - 1) / (2 * lanes));
     auto width = [&](int np_) {
       int bb = (int)((l + 2 * np_ - 1) / (2 * np_));
       return bb + (bb & 1);
@@ -631,20 +639,20 @@ class HipDev {
     if (np <= 0) {
       // fewest workgroups whose block pair fits one CU (<= 32 processors, LDS): fewer, larger steps per sweep
       np = 2;
-      while (np < 128 && (width(np) > jmc_max_b_ || k::jmc_lds_bytes(nc, width(np), sizeof(T)) > (size_t)160 * 1024)) ++np;
+      while (np < 128 && (width(np) > jmc_max_b_ || k::jmc_lds_bytes(nc, width(np), sizeof(T), lanes) > (size_t)160 * 1024)) ++np;
     }
     const int b = width(np);
-    if (np < 1 || b < 2 || b > 32 || k::jmc_lds_bytes(nc, b, sizeof(T)) > (size_t)160 * 1024) return false;
+    if (np < 1 || b < 2 || b > 32 || k::jmc_lds_bytes(nc, b, sizeof(T), lanes) > (size_t)160 * 1024) return false;
     *nc_out = nc;
     *np_out = np;
     *b_out = b;
     return true;
   }
   template <class T, int NC>
-  void jmc_launch_step(int np, int b, T* w, T* v, int nblocks, int step, int sweep, T tol, T tol_early, k::JmcCtl* ctl) {
-    const size_t lds = k::jmc_lds_bytes(NC, b, sizeof(T));
-    const unsigned threads = (unsigned)((b * k::kJmcLanes + 63) / 64 * 64);
-    hipLaunchKernelGGL((k::jmc_step_kernel<T, NC>), dim3((unsigned)np), dim3(threads), lds, stream, w, v, b, nblocks, step,
+  void jmc_launch_step(int lanes, int np, int b, T* w, T* v, int nblocks, int step, int sweep, T tol, T tol_early, k::JmcCtl* ctl) {
+    const size_t lds = k::jmc_lds_bytes(NC, b, sizeof(T), lanes);
+    const unsigned threads = (unsigned)((b * lanes + 63) / 64 * 64);
+    hipLaunchKernelGGL((k::jmc_step_kernel<T, NC, 16>), dim3((unsigned)np), dim3(threads), lds, stream, w, v, b, nblocks, step,
                        sweep, step == 0 ? 1 : 0, tol, tol_early, ctl);
   }
   // conv_status: device CholStatus record that receives the convergence verdict of the fixed number of sweeps
@@ -655,7 +663,8 @@ class HipDev {
     int nc = 0, np = 0, b = 0;
     if (!jmc_geometry<T>(l, &nc, &np, &b)) throw Error(ST_EINVAL, "internal: core too large for the multi-workgroup Jacobi");
     // global column pitch = LDS column pitch: a block of b columns is one contiguous byte range in both
-    const int rp = k::jmc_pitch(nc, (int)sizeof(T)), nblocks = 2 * np, ncols_pad = nblocks * b;
+    const int lanes = jmc_lanes<T>(l);
+    const int rp = k::jmc_pitch(nc, (int)sizeof(T), lanes), nblocks = 2 * np, ncols_pad = nblocks * b;
     T* wj = (T*)alloc_bytes((size_t)rp * ncols_pad * sizeof(T));
     T* vj = (T*)alloc_bytes((size_t)rp * ncols_pad * sizeof(T));
     k::JmcCtl* ctl = (k::JmcCtl*)alloc_bytes(sizeof(k::JmcCtl));
@@ -675,15 +684,15 @@ class HipDev {
     auto enqueue_sweeps = [&](int s0, int s1) {
       for (int sw = s0; sw < s1; ++sw)
         for (int step = 0; step < nblocks - 1; ++step) switch (nc) {
-            case 1: jmc_launch_step<T, 1>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 2: jmc_launch_step<T, 2>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 3: jmc_launch_step<T, 3>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 4: jmc_launch_step<T, 4>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 5: jmc_launch_step<T, 5>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 6: jmc_launch_step<T, 6>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 7: jmc_launch_step<T, 7>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 8: jmc_launch_step<T, 8>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            default: jmc_launch_step<T, 9>(np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 1: jmc_launch_step<T, 1>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 2: jmc_launch_step<T, 2>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 3: jmc_launch_step<T, 3>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 4: jmc_launch_step<T, 4>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 5: jmc_launch_step<T, 5>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 6: jmc_launch_step<T, 6>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 7: jmc_launch_step<T, 7>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 8: jmc_launch_step<T, 8>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            default: jmc_launch_step<T, 9>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
           }
       CORRLA_HIP(hipGetLastError());
     };

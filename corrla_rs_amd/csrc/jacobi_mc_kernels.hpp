@@ -28,7 +28,6 @@ namespace corrla {
 namespace k {
 
 constexpr int kJmcMaxSweeps = 40;
-constexpr int kJmcLanes = 16;  // lanes per processor (one DPP row)
 constexpr float kJmcFastCond = 16.f;   // W-only mode when max |diag| <= 16 min |diag| ...
 constexpr float kJmcVerifyCond = 64.f; // ... and accepted when the computed sigma_max <= 64 sigma_min
 struct JmcCtl {
@@ -58,8 +57,13 @@ struct JmcVec<double> {
   typedef double v2 __attribute__((ext_vector_type(2)));
 };
 
-__device__ __forceinline__ float jmc_sum16(float x) { return group_sum<16>(x); }
-__device__ __forceinline__ double jmc_sum16(double x) {
+template <int LANES>
+__device__ __forceinline__ float jmc_sum(float x) {
+  return group_sum<LANES>(x);
+}
+template <int LANES>
+__device__ __forceinline__ double jmc_sum(double x) {
+  static_assert(LANES == 16, "f64 processors are 16 lanes wide");
   auto dpp = [](double v, auto ctrl) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(0, lo, decltype(ctrl)::value, 0xf, 0xf, true);
@@ -73,17 +77,19 @@ __device__ __forceinline__ double jmc_sum16(double x) {
   return x;
 }
 
-// rows per column image: NC chunk rows of 16 lanes x 2 elements
-__host__ __device__ constexpr int jmc_rows(int nc) { return nc * 2 * kJmcLanes; }
-// LDS column pitch (elements): b64 reads (f32) are serviced per 32-lane half = two processors, whose 128-byte
-// segments must fall in different halves of the 256-byte bank row -> pitch = 32 (mod 64); b128 reads (f64) are
-// serviced in interleaved 16-lane groups that mix two processors -> their columns must be bank-aligned, pitch = 0
-// (mod 32)
-__host__ __device__ constexpr int jmc_pitch(int nc, int esz) {
-  return esz == 4 ? (jmc_rows(nc) + ((nc % 2 == 0) ? 32 : 0)) : jmc_rows(nc);
+// rows per column image: NC chunk rows of `lanes` lanes x 2 elements
+__host__ __device__ constexpr int jmc_rows(int nc, int lanes) { return nc * 2 * lanes; }
+// LDS column pitch (elements).  16 lanes per processor: b64 reads (f32) are serviced per 32-lane half = two
+// processors, whose 128-byte segments must fall in different halves of the 256-byte bank row -> pitch = 32 (mod 64);
+// b128 reads (f64) are serviced in interleaved 16-lane groups that mix two processors -> their columns must be
+// bank-aligned, pitch = 0 (mod 32).  8 lanes per processor (f32 only): a 32-lane half is four processors reading 64
+// bytes each from four (mostly consecutive) columns -> pitch = 16 or 48 (mod 64).
+__host__ __device__ constexpr int jmc_pitch(int nc, int esz, int lanes) {
+  return lanes == 8 ? (jmc_rows(nc, 8) + ((nc % 2 == 0) ? 16 : 0))
+                    : (esz == 4 ? (jmc_rows(nc, 16) + ((nc % 2 == 0) ? 32 : 0)) : jmc_rows(nc, 16));
 }
-__host__ __device__ constexpr size_t jmc_lds_bytes(int nc, int b, int esz) {
-  return (size_t)2 * (2 * b) * jmc_pitch(nc, esz) * esz + (size_t)2 * b * esz + 64;
+__host__ __device__ constexpr size_t jmc_lds_bytes(int nc, int b, int esz, int lanes) {
+  return (size_t)2 * (2 * b) * jmc_pitch(nc, esz, lanes) * esz + (size_t)2 * b * esz + 64;
 }
 
 // W <- 2^sexp * C (zero padded to rp x ncols_pad, rp = the LDS column pitch so that a block of columns is ONE
@@ -162,12 +168,13 @@ __global__ __launch_bounds__(1024) void jmc_init_kernel(const T* __restrict__ c,
   }
 }
 
-// One outer step.  grid = NP workgroups, block = b * 16 threads (rounded up to a wave; b <= 32, b even).
-template <class T, int NC>
+// One outer step.  grid = NP workgroups, block = b * LANES threads (rounded up to a wave; b <= 32, b even).
+// LANES = 16 is what runs; 8 (f32 only: half the waves per block pair, twice the column per lane) measured slower.
+template <class T, int NC, int LANES>
 __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nblocks, int step, int sweep, int within,
                                                         T tol, T tol_early, JmcCtl* ctl) {
   typedef typename JmcVec<T>::v2 v2;
-  constexpr int PITCH = jmc_pitch(NC, (int)sizeof(T));
+  constexpr int PITCH = jmc_pitch(NC, (int)sizeof(T), LANES);
   // converged in an earlier sweep (the flags were written by earlier launches): nothing to do
   if (sweep > 0 && !(ctl->rot[sweep - 1] && ctl->big[sweep - 1])) return;
   if (threadIdx.x == 0 && blockIdx.x == 0 && ctl->t_last != 0) {  // diagnostic: span of the PREVIOUS launch
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
   int* flag = (int*)(nrm + 2 * b);         // [2]; everything in the dynamic region: a static __shared__ would shift
                                            // its base off 16 bytes (cdna_hip_programming.md Guideline 17)
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int proc = tid / kJmcLanes, g = tid % kJmcLanes;
+  const int proc = tid / LANES, g = tid % LANES;
   const bool act = proc < b;
   int bp, bq;
   tournament_pair(nblocks, step, blockIdx.x, bp, bq);
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
   }
   __syncthreads();
   const long long ts1 = wall_clock64();
-  // per-lane chunk offsets (elements): chunk c of lane g covers rows (c * 16 + g) * 2 + {0, 1}
+  // per-lane chunk offsets (elements): chunk c of lane g covers rows (c * LANES + g) * 2 + {0, 1}
   const int lane_off = g * 2;
   // ---- squared norms of the local columns: processor i takes slots i and b + i ----
   if (act) {
@@ -223,11 +230,11 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
       T a0 = 0, a1 = 0;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const v2 x = *(const v2*)(col + c * 2 * kJmcLanes);
+        const v2 x = *(const v2*)(col + c * 2 * LANES);
         a0 += x[0] * x[0];
         a1 += x[1] * x[1];
       }
-      const T a = jmc_sum16(a0 + a1);
+      const T a = jmc_sum<LANES>(a0 + a1);
       if (g == 0) nrm[s] = a;
     }
   }
@@ -241,35 +248,35 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
     v2 x[NC], y[NC], vx[NC], vy[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      x[c] = *(const v2*)(cx + c * 2 * kJmcLanes);
-      y[c] = *(const v2*)(cy + c * 2 * kJmcLanes);
+      x[c] = *(const v2*)(cx + c * 2 * LANES);
+      y[c] = *(const v2*)(cy + c * 2 * LANES);
     }
     if (with_v) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        vx[c] = *(const v2*)(ux + c * 2 * kJmcLanes);
-        vy[c] = *(const v2*)(uy + c * 2 * kJmcLanes);
+        vx[c] = *(const v2*)(ux + c * 2 * LANES);
+        vy[c] = *(const v2*)(uy + c * 2 * LANES);
       }
     }
     T na = nrm[sx], nb = nrm[sy];
     v2 acc = x[0] * y[0];
 #pragma unroll
     for (int c = 1; c < NC; ++c) acc += x[c] * y[c];
-    const T gg = jmc_sum16(acc[0] + acc[1]);
+    const T gg = jmc_sum<LANES>(acc[0] + acc[1]);
     T cs, sn, rel, t;
     if (jacobi_rotation(na, nb, gg, tol, cs, sn, rel, t)) {  // uniform over the 16 lanes of a processor
       my_rot = 1;
       if (rel > tol_early) my_big = 1;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        *(v2*)(cx + c * 2 * kJmcLanes) = cs * x[c] - sn * y[c];
-        *(v2*)(cy + c * 2 * kJmcLanes) = sn * x[c] + cs * y[c];
+        *(v2*)(cx + c * 2 * LANES) = cs * x[c] - sn * y[c];
+        *(v2*)(cy + c * 2 * LANES) = sn * x[c] + cs * y[c];
       }
       if (with_v) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          *(v2*)(ux + c * 2 * kJmcLanes) = cs * vx[c] - sn * vy[c];
-          *(v2*)(uy + c * 2 * kJmcLanes) = sn * vx[c] + cs * vy[c];
+          *(v2*)(ux + c * 2 * LANES) = cs * vx[c] - sn * vy[c];
+          *(v2*)(uy + c * 2 * LANES) = sn * vx[c] + cs * vy[c];
         }
       }
       if (g == 0) {
@@ -281,11 +288,73 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
   const long long clk0 = clock64(), wall0 = wall_clock64();
   const long long ts2 = wall0;
   // ---- cross rounds: every column of P meets every column of Q ----
-  for (int r = 0; r < b; ++r) {
+  // Processor i keeps column P[i] (and its V column, and its squared norm) in registers for all b rounds: only the Q
+  // column of a round crosses LDS.
+  {
+    T* cx = wl + (size_t)proc * PITCH + lane_off;
+    T* ux = vl + (size_t)proc * PITCH + lane_off;
+    v2 x[NC], vx[NC];
+    T na = 0;
     if (act) {
-      int sy = proc + r;
-      if (sy >= b) sy -= b;
-      round(proc, b + sy);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) x[c] = *(const v2*)(cx + c * 2 * LANES);
+      if (with_v) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) vx[c] = *(const v2*)(ux + c * 2 * LANES);
+      }
+      na = nrm[proc];
+    }
+    for (int r = 0; r < b; ++r) {
+      if (act) {
+        int sy = proc + r;
+        if (sy >= b) sy -= b;
+        sy += b;
+        T* cy = wl + (size_t)sy * PITCH + lane_off;
+        T* uy = vl + (size_t)sy * PITCH + lane_off;
+        v2 y[NC], vy[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) y[c] = *(const v2*)(cy + c * 2 * LANES);
+        if (with_v) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) vy[c] = *(const v2*)(uy + c * 2 * LANES);
+        }
+        const T nb = nrm[sy];
+        v2 acc = x[0] * y[0];
+#pragma unroll
+        for (int c = 1; c < NC; ++c) acc += x[c] * y[c];
+        const T gg = jmc_sum<LANES>(acc[0] + acc[1]);
+        T cs, sn, rel, t;
+        if (jacobi_rotation(na, nb, gg, tol, cs, sn, rel, t)) {  // uniform over the lanes of a processor
+          my_rot = 1;
+          if (rel > tol_early) my_big = 1;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const v2 xn = cs * x[c] - sn * y[c];
+            *(v2*)(cy + c * 2 * LANES) = sn * x[c] + cs * y[c];
+            x[c] = xn;
+          }
+          if (with_v) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const v2 xn = cs * vx[c] - sn * vy[c];
+              *(v2*)(uy + c * 2 * LANES) = sn * vx[c] + cs * vy[c];
+              vx[c] = xn;
+            }
+          }
+          na -= t * gg;
+          if (g == 0) nrm[sy] = nb + t * gg;
+        }
+      }
+      __syncthreads();
+    }
+    if (act) {  // the columns go back to the LDS image (stored to global memory from there)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) *(v2*)(cx + c * 2 * LANES) = x[c];
+      if (with_v) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) *(v2*)(ux + c * 2 * LANES) = vx[c];
+      }
+      if (g == 0) nrm[proc] = na;
     }
     __syncthreads();
   }
