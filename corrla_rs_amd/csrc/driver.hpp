@@ -5,6 +5,7 @@
 // orthonormalisation passes, sharded exchange points) without a GPU.  No arithmetic on m- or
 // n-sized data happens in this file.
 #pragma once
+#include <cstdio>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -190,7 +191,16 @@ struct RsvdDriver {
     int slot, npass;
     bool rough;
     int per_pass;  // status records per pass: 1 (single factorisation) or 2 (2 x 2 blocked)
+    void* st = nullptr;  // scratch status records of a device-robust thin-Q (diagnostics only)
+    bool is_svd = false; // the convergence verdict of the core SVD's fixed number of sweeps
+    int flag_slot = -1;  // >= 0: a device-robust Cholesky-QR (orthonormalize_device); clean iff flags[flag_slot + npass - 1] == 0
   };
+  static constexpr int kRobustPasses = 8;  // most passes a device-robust thin-Q enqueues (2 always, the rest conditional)
+  bool robust_needs_more_ = false;         // pending_clean: a device-robust thin-Q ran out of enqueued passes
+  bool svd_needs_more_ = false;            // pending_clean: the core SVD ran out of enqueued sweeps
+  int* flags_pool_ = nullptr;              // device words: need_next of every pass of every robust thin-Q of the call
+  int flags_cap_ = 0, flags_used_ = 0;
+  int qr_site_ = 0;  // DEBUG bisect
   bool defer_status_ = false;
   bool optimistic_dirty_ = false;  // a pass of the optimistic run took the host-controlled loop: repeat the call
   void* st_pool_ = nullptr;
@@ -247,9 +257,88 @@ struct RsvdDriver {
     return r + rc;
   }
 
-  int64_t orthonormalize_core(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough) {
+  // Thin-Q without the host, whatever the conditioning or rank of the sketch (optimistic runs, l <= 144): iterated
+  // Cholesky-QR in which the DEVICE decides what a pass does (k::chol_inv_kernel, robust form):
+  //   pass 1     G = Y^T Y, shifted Cholesky (G + s I never breaks down; Y R_s^-1 keeps the span and lifts the weak
+  //              directions by up to 1 / sqrt(s_rel) relative to the strong ones),
+  //   pass 2..   shifted again while the Gram is further than 0.25 from I, plain Cholesky once it is within (the
+  //              product of that pass is orthonormal to O(eps)), a first-order (I + E)^(-1/2) when it is within 2e-4;
+  //              an exactly zero column (or a pivot that fails despite the shift) is a NULL column: a zero column of
+  //              R^-1, replaced by a random column after the product,
+  //   pass 3..P  carry the need_next word of the pass before as the run_if of every launch: nothing happens once a
+  //              pass has seen a Gram within 0.25 of I and produced no null column.
+  // Well-conditioned sketches cost what CholeskyQR2 cost plus a few empty launches; ill-conditioned and rank-deficient
+  // ones no longer repeat the whole call through the host-controlled loop (16384^2 f32 with sigma_i = 0.97^i:
+  // 11.5 ms, sigma_i = 0.7^i: 37 ms, against 5.1 ms for a flat spectrum).  All products run in place (every
+  // workgroup / wave reads exactly the rows it writes, and all of them before it stores).  `rough` (in-loop,
+  // random_svd.rs:37-39): pass 1 only.  The verdict -- need_next of the last pass must be 0 -- is read with the
+  // status records at the end of the call; a sketch that needs more passes than were enqueued repeats on the old path.
+  // `polish`: the input is expected to be orthonormal already up to a small defect (the W / sigma factor of the core
+  // SVD): no shift, and every pass after the first is conditional.
+  int64_t orthonormalize_device(Skinny<T>& y, bool sharded, bool rough, bool polish) {
+    const int64_t l = y.cols;
+    PhaseTimer qt0;
+    // how many passes are enqueued is a property of the CONTEXT: it starts at the two (polish: one) a well-conditioned
+    // sketch needs -- no conditional launch at all -- and doubles (2 -> 4 -> 8) whenever a call ends with a thin-Q
+    // still asking for more; the call is then repeated on the device with the higher count (random_svd_tall)
+    const int level = std::max(2, std::min(dev.robust_passes(), kRobustPasses));
+    const int npass = (rough && !polish) ? 1 : (polish ? (level <= 2 ? 1 : 3) : level);
+    const int always = polish ? 1 : 2;
+    int* need = flags_pool_ + flags_used_;
+    int* null_mask = dev.alloc_flags((int)l);
+    void* st_scratch = dev.alloc_zeroed_bytes((size_t)npass * kStatusBytes);
+    Skinny<T> gd = dev.template alloc_skinny<T>(l, l);
+    Skinny<T> md = dev.template alloc_skinny<T>(l, l);
+    const double eps0 = (double)std::numeric_limits<T>::epsilon();
+    // shift: as small as the rounding error of the computed Gram allows (~ eps sqrt(m) relative to its largest diagonal
+    // entry; never below the 16 eps of the host-controlled path).  A small shift lifts the weak directions further per
+    // pass AND keeps them more accurate (16384 x 16384 f32, sigma_i = 0.7^i: the 10th singular value to 1.6e-5 with
+    // 16 eps, to 2.3e-4 with 1100 eps); a pivot that fails all the same only costs that column (null -> re-seeded).
+    double shift_rel = eps0 * std::max(16.0, 0.25 * std::sqrt((double)std::max<int64_t>(y.rows, 1)));
+    if (const char* e = std::getenv("CORRLA_DBG_SHIFT_SCALE")) shift_rel *= std::atof(e);
+    // in-loop: a direction whose residual is below the shift would leave the pass less than half normalised; such
+    // half-lifted columns measurably hurt (DMDc snapshots: 7e-7 instead of 1e-14 in the 8th singular vector), so they
+    // are re-seeded at random like the completion of the host-controlled path (which drops below 1e-2)
+    float nullx = 1.f;
+    if (const char* e = std::getenv("CORRLA_DBG_NULLX")) nullx = (float)std::atof(e);
+    for (int pass = 0; pass < npass; ++pass) {
+      dev.set_run_if(pass < always ? nullptr : need + pass - 1);
+      Skinny<T> yv = y.view_cols(l);
+      dev.gemm_nn(as_rowmajor_transposed(y, l), yv, gd, kNone);
+      if (sharded) dev.allreduce(gd.p, (size_t)gd.ld * (size_t)gd.cols_alloc);  // unconditional: ranks stay in step
+      // in-loop (rough): directions below the level one shifted pass can lift are re-seeded at random, like the
+      // completion of the host-controlled path -- the next products with A pull the re-seeded columns back into range(A)
+      // (final thin-Q: the first two passes only lift; what is still below the shift level in the third has no
+      // independent information -- amplified rounding noise is not even linearly independent, it would be lifted and
+      // crushed again for ever -- and is re-seeded too)
+      dev.chol_inv_robust(gd, l, (T)(4.0 * eps0), (float)shift_rel, polish ? 2 : (pass == 0 ? 1 : 0),
+                          ((rough && !polish) || (!polish && pass >= 2)) ? nullx : 0.f,
+                          md, st_scratch, pass, need + pass, null_mask);
+      dev.apply_inplace(y, l, md);
+      // (a re-seeded column needs a following pass to be orthonormalised: none after the last one)
+      if (pass + 1 < npass || npass == 1) dev.refill_null(y, l, null_mask, (uint64_t)(0x9e3779b97f4a7c15ull ^ (uint64_t)(977 * (flags_used_ + pass) + l)));
+      if (pass < always) ++tm.qr_passes;  // the conditional ones are counted when the flags are read (pending_clean)
+    }
+    dev.set_run_if(nullptr);
+    Pending pd{always, npass, rough, 0};
+    pd.st = st_scratch;
+    pd.flag_slot = (rough && !polish) ? -1 : flags_used_;
+    pending_.push_back(pd);
+    flags_used_ += npass;
+    subphase(tm.qr_gram_ms, qt0);
+    return l;
+  }
+
+  int64_t orthonormalize_core(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough, bool polish = false) {
     const int64_t l = y.cols;
     int64_t r = l;
+    // (sharded: the LOCAL row count says nothing -- and differs between ranks, which must all take the same branch;
+    // a matrix with fewer global rows than l ends with need_next still set and repeats on the host-controlled path)
+    const char* dbg_mask = std::getenv("CORRLA_DBG_ROBUST_MASK");
+    const bool dbg_ok = !dbg_mask || (std::atoi(dbg_mask) & qr_site_);
+    if (dbg_ok && defer_status_ && (sharded || y.rows >= l) && flags_used_ + kRobustPasses <= flags_cap_ &&
+        dev.template device_qr_robust_fits<T>(l))
+      return orthonormalize_device(y, sharded, rough, polish);
     if (dev.template device_chol_fits<T>(l)) {
       // Optimistic CholeskyQR2 entirely on the device: [Gram, Cholesky + inverse, apply] x2 are enqueued
       // back to back and the two status records are read once at the end.  Anything unusual (a failed
@@ -504,6 +593,7 @@ struct RsvdDriver {
     for (int64_t i = i0; i < n_iter; ++i) {  // :35
       if (i > 2) {                          // :37-39
         phase(tm.power_ms, pt);
+        qr_site_ = 1;
         orthonormalize(y, y2, o.sharded, /*rough=*/true);
         phase(tm.qr_ms, pt);
       }
@@ -520,6 +610,7 @@ struct RsvdDriver {
       a_times(a, z, y, kNone);              // :47-51
     }
     phase(tm.power_ms, pt);
+    qr_site_ = 2;
     int64_t r = orthonormalize(y, y2, o.sharded);  // :57
     phase(tm.qr_ms, pt);
     return r;
@@ -543,24 +634,40 @@ struct RsvdDriver {
       // (no host synchronisation inside the call).  A record that is not clean (rank deficiency, zero or
       // non-finite input, ...) repeats the computation with the host in the loop.
       const Timings saved = tm;
-      // records: <= 2 per pass x <= 2 passes for each of the max(0, q - 3) in-loop, the final and the B^T thin-Q
-      st_slots_ = (int)std::min<int64_t>(4 * (std::max<int64_t>(0, n_iter - 3) + 2) + 1, 4096);  // + the core SVD's
-      st_pool_ = dev.alloc_bytes((size_t)st_slots_ * kStatusBytes);
-      st_used_ = 0;
-      pending_.clear();
-      optimistic_dirty_ = false;
-      defer_status_ = true;
-      try {
-        random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
-      } catch (...) {
+      for (int attempt = 0; attempt < 5; ++attempt) {
+        // records: <= 2 per pass x <= 2 passes for each of the max(0, q - 3) in-loop, the final and the B^T thin-Q
+        st_slots_ = (int)std::min<int64_t>(4 * (std::max<int64_t>(0, n_iter - 3) + 2) + 1, 4096);  // + the core SVD's
+        st_pool_ = dev.alloc_bytes((size_t)st_slots_ * kStatusBytes);
+        st_used_ = 0;
+        flags_cap_ = kRobustPasses * (int)std::min<int64_t>(std::max<int64_t>(0, n_iter - 3) + 4, 1024);
+        flags_pool_ = dev.alloc_flags(flags_cap_);
+        flags_used_ = 0;
+        pending_.clear();
+        optimistic_dirty_ = false;
+        robust_needs_more_ = false;
+        svd_needs_more_ = false;
+        defer_status_ = true;
+        try {
+          random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
+        } catch (...) {
+          defer_status_ = false;
+          throw;
+        }
         defer_status_ = false;
-        throw;
+        if (emit) emit();
+        if (pending_clean()) return;
+        tm = saved;
+        dev.phase_forget();  // the abandoned run still counts in total_ms, not in the phase slots
+        // a thin-Q that only ran out of enqueued passes: enqueue more from now on (this context) and repeat on the device
+        if (optimistic_dirty_) break;
+        if (robust_needs_more_ && dev.robust_passes() < kRobustPasses) {
+          dev.set_robust_passes(std::min(kRobustPasses, 2 * std::max(2, dev.robust_passes())));
+        } else if (svd_needs_more_ && dev.svd_more_sweeps()) {
+          // the context enqueues more Jacobi sweeps from now on; repeat on the device
+        } else {
+          break;
+        }
       }
-      defer_status_ = false;
-      if (emit) emit();
-      if (pending_clean()) return;
-      tm = saved;
-      dev.phase_forget();  // the abandoned run still counts in total_ms, not in the phase slots
     }
     random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
     if (emit) emit();
@@ -571,8 +678,35 @@ struct RsvdDriver {
     if (pending_.empty()) return true;
     std::vector<int> fail((size_t)st_used_);
     std::vector<float> min_ratio((size_t)st_used_), dev_i((size_t)st_used_);
-    dev.read_chol_status(st_pool_, st_used_, fail.data(), min_ratio.data(), dev_i.data());
+    if (st_used_ > 0) dev.read_chol_status(st_pool_, st_used_, fail.data(), min_ratio.data(), dev_i.data());
+    std::vector<int> flags((size_t)flags_used_);
+    if (flags_used_ > 0) dev.read_flags(flags_pool_, flags_used_, flags.data());
     for (const Pending& p : pending_) {
+      if (p.flag_slot >= 0) {  // device-robust thin-Q: its last enqueued pass must not ask for another one
+        // (p.slot = number of unconditional passes; conditional pass i ran iff pass i - 1 asked for it)
+        for (int i = p.slot; i < p.npass; ++i)
+          if (flags[(size_t)p.flag_slot + i - 1] != 0) ++tm.qr_passes;
+        if (std::getenv("CORRLA_DEBUG")) {
+          std::fprintf(stderr, "[corrla] device thin-Q: %d passes enqueued, need_next =", p.npass);
+          for (int i = 0; i < p.npass; ++i) std::fprintf(stderr, " %d", flags[(size_t)p.flag_slot + i]);
+          std::vector<int> f2((size_t)p.npass);
+          std::vector<float> mr((size_t)p.npass), di((size_t)p.npass);
+          dev.read_chol_status(p.st, p.npass, f2.data(), mr.data(), di.data());
+          std::fprintf(stderr, "; ||G - I||_max / min pivot ratio per pass:");
+          for (int i = 0; i < p.npass; ++i) std::fprintf(stderr, " %.2g/%.2g", di[(size_t)i], mr[(size_t)i]);
+          std::fprintf(stderr, "\n");
+        }
+        if (flags[(size_t)p.flag_slot + p.npass - 1] != 0) {
+          robust_needs_more_ = true;
+          return false;
+        }
+        continue;
+      }
+      if (p.rough && p.per_pass == 0) continue;  // one shifted pass in-loop: nothing to verify
+      if (p.is_svd && fail[(size_t)p.slot] == 1) {  // not converged within the sweeps that were enqueued
+        svd_needs_more_ = true;
+        return false;
+      }
       for (int i = 0; i < p.npass * p.per_pass; ++i)
         if (fail[p.slot + i] != 0) return false;
       if (!p.rough)
@@ -601,6 +735,7 @@ struct RsvdDriver {
     Skinny<T> qb = dev.template alloc_skinny<T>(a.nt, l);
     Skinny<T> qb2 = dev.template alloc_skinny<T>(a.nt, l);
     dev.copy_skinny(bt, qb);
+    qr_site_ = 4;
     orthonormalize(qb, qb2, false);
     phase(tm.qr_ms, pt);
     // The core is formed TRANSPOSED, C^T = B Qb = (Qb^T B^T)^T: C is the triangular factor R of B^T = Qb R (up to
@@ -617,6 +752,7 @@ struct RsvdDriver {
       // kernels that run a fixed number of sweeps report convergence here; checked with the Cholesky records
       svd_st = (void*)((char*)st_pool_ + (size_t)st_used_ * kStatusBytes);
       pending_.push_back({st_used_, 1, true, 1});
+      pending_.back().is_svd = true;
       st_used_ += 1;
     }
     dev.small_svd(ct, l, k, m2, m1, s_dev, svd_st);
@@ -628,7 +764,8 @@ struct RsvdDriver {
       // triplets move by less than their own uncertainty.  (The accumulated-rotation factor m2 is orthogonal by
       // construction.)  A rank-deficient core fails the pass and the call repeats on the host-controlled path.
       Skinny<T> m1b = dev.template alloc_skinny<T>(l, k);
-      orthonormalize_core(m1, m1b, false, /*rough=*/true);
+      qr_site_ = 8;
+      orthonormalize_core(m1, m1b, false, /*rough=*/true, /*polish=*/true);
     }
     if (!defer_status_) {
       // Exactly singular core (rank-deficient or zero input; only reachable through the host-controlled path): the

@@ -111,6 +111,8 @@ class HipDev {
     jmc_min_l_ = env_int("CORRLA_JMC_MIN_L", 96);  // below: the single-workgroup ring kernel + replay is as fast (one launch)
     jmc_max_b_ = std::min(32, std::max(2, env_int("CORRLA_JMC_MAX_B", 24)));
     tall_min_rows_ = env_int("CORRLA_TALL_MIN_ROWS", 65536);  // 0: the general kernels everywhere
+    robust_passes_ = std::max(2, env_int("CORRLA_ROBUST_PASSES", 2));
+    robust_qr_ = env_int("CORRLA_DEVICE_ROBUST_QR", 1) != 0;  // 0: the round-1 optimistic CholeskyQR2 + host-controlled repeat
     persist_max_tiles_ = env_int("CORRLA_GEMM_PERSIST_TILES", 16);  // 0: one workgroup per outer tile everywhere
     gemm_debug_flags_ = env_int("CORRLA_GEMM_DEBUG", 0);  // timing-only ablations, results are wrong
   }
@@ -367,7 +369,7 @@ class HipDev {
       dim3 rgd((unsigned)((a.cols + 63) / 64), (unsigned)cb.cols_alloc);
       check_grid(rgd);
       hipLaunchKernelGGL((k::slab_reduce_deep_kernel<float>), rgd, dim3(256), 0, stream, (const float*)g.slab, g.slab_stride, nrg,
-                         z.p, z.ld, a.cols, cb.cols_alloc, (const float*)nullptr);
+                         z.p, z.ld, a.cols, cb.cols_alloc, (const float*)nullptr, (const int*)nullptr);
       CORRLA_HIP(hipGetLastError());
     }
   }
@@ -508,6 +510,54 @@ class HipDev {
                        m_out.ld, (k::CholStatus*)st_dev + slot);
     CORRLA_HIP(hipGetLastError());
   }
+  // ---- device-robust Cholesky-QR (driver.hpp: orthonormalize_device) ----
+  // every launch enqueued while a run_if word is set does nothing when that device word is 0
+  void set_run_if(const int* p) { run_if_ = p; }
+  // passes a device-robust thin-Q enqueues on this context (driver.hpp: orthonormalize_device); grows on demand
+  int robust_passes() const { return robust_passes_; }
+  void set_robust_passes(int n) { robust_passes_ = n; }
+  // the core SVD of a call did not converge within the sweeps enqueued: enqueue 8 more from now on (false: at the cap)
+  bool svd_more_sweeps() {
+    if (jmc_extra_sweeps_ >= 24) return false;
+    jmc_extra_sweeps_ += 8;
+    return true;
+  }
+  int* alloc_flags(int n) { return (int*)alloc_zeroed(sizeof(int) * (size_t)std::max(n, 1)); }
+  void* alloc_zeroed_bytes(size_t bytes) { return alloc_zeroed(bytes); }
+  void read_flags(const int* dev_p, int n, int* host) {
+    CORRLA_HIP(hipMemcpyAsync(host, dev_p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    sync();
+  }
+  template <class T>
+  bool device_qr_robust_fits(int64_t l) const {
+    return robust_qr_ && device_chol_fits<T>(l) && col_blocking(l).nblk == 1;
+  }
+  template <class T>
+  void chol_inv_robust(const Skinny<T>& g, int64_t r, T piv_rel, float shift_rel, int shift_mode, float null_excess,
+                       Skinny<T>& m_out, void* st_dev, int slot, int* need_next, int* null_mask) {
+    k::CholRobust rb{shift_rel, shift_mode, null_excess, need_next, null_mask, run_if_};
+    hipLaunchKernelGGL((k::chol_inv_kernel<T>), dim3(1), dim3(k::chol_inv_threads((int)r)),
+                       k::chol_inv_lds_bytes((int)r, sizeof(T)), stream, (const T*)g.p, g.ld, (int)r, piv_rel, m_out.p,
+                       m_out.ld, (k::CholStatus*)st_dev + slot, rb);
+    CORRLA_HIP(hipGetLastError());
+  }
+  // y <- y * m (m: l x l): in place -- a workgroup / wave of the product kernels reads exactly the rows it writes,
+  // all of them before its first store (one column block only: device_qr_robust_fits)
+  template <class T>
+  void apply_inplace(Skinny<T>& y, int64_t l, const Skinny<T>& m) {
+    Skinny<T> out = y.view_cols(l);
+    Skinny<T> mv = m.view_cols(l);
+    mv.rows = l;
+    launch_gemm<T>(true, as_rowmajor_transposed(y, l), mv, out, (const T*)nullptr, y.rows, l);
+  }
+  template <class T>
+  void refill_null(Skinny<T>& y, int64_t l, const int* null_mask, uint64_t seed) {
+    const int bx = (int)std::min<int64_t>(64, (y.rows + 255) / 256);
+    hipLaunchKernelGGL((k::refill_null_kernel<T>), dim3((unsigned)std::max(bx, 1), (unsigned)l), dim3(256), 0, stream, y.p, y.ld,
+                       y.rows, (int)l, null_mask, seed, run_if_);
+    CORRLA_HIP(hipGetLastError());
+  }
+
   void read_chol_status(const void* st_dev, int n, int* fail, float* min_ratio, float* dev_i) {
     static_assert(sizeof(k::CholStatus) == 32, "driver.hpp assumes 32-byte status records");
     std::vector<k::CholStatus> h((size_t)std::max(n, 1));
@@ -707,7 +757,7 @@ class HipDev {
       CORRLA_HIP(hipGetLastError());
     };
     if (conv_status) {
-      const int nsw = std::min(k::kJmcMaxSweeps, std::max(1, env_int("CORRLA_JMC_SWEEPS", sizeof(T) == 4 ? 10 : 13)));
+      const int nsw = std::min(k::kJmcMaxSweeps, std::max(1, env_int("CORRLA_JMC_SWEEPS", sizeof(T) == 4 ? 10 : 13)) + jmc_extra_sweeps_);
       enqueue_sweeps(0, nsw);
       finish(nsw);
       if (env_int("CORRLA_DEBUG", 0)) {
@@ -1159,6 +1209,10 @@ class HipDev {
   bool no_device_chol_ = false;
   int jmc_min_l_ = 96, jmc_max_b_ = 24;
   int persist_max_tiles_ = 16;
+  const int* run_if_ = nullptr;
+  bool robust_qr_ = true;
+  int robust_passes_ = 2;
+  int jmc_extra_sweeps_ = 0;
   int64_t tall_min_rows_ = 65536;
 
   static void check_grid(const dim3& g) {
@@ -1305,6 +1359,7 @@ class HipDev {
       g.out_cols = (int)(out.external ? out.cols : std::min<int64_t>(out.cols_alloc, 16 * kt));
       g.scale = scale_dev;
       g.vec_store = ((out.ld % kVecElems) == 0 && ((uintptr_t)out.p % 16) == 0) ? 1 : 0;
+      g.run_if = run_if_;
       const int64_t nblocks = (m + 16 * kVecElems - 1) / (16 * kVecElems);
       dim3 grid((unsigned)std::min<int64_t>((nblocks + 3) / 4, num_cus));
       switch (kt) {
@@ -1346,6 +1401,7 @@ class HipDev {
     g.out_ld = out.ld;
     g.rows_per_group = rpg;
     g.zero = (const T*)zero_page_;
+    g.run_if = run_if_;
     dim3 grid((unsigned)ngroups);
     switch (nct) {
       case 1: launch_tall_gram<T, 1>(grid, g); break;
@@ -1364,7 +1420,7 @@ class HipDev {
     CORRLA_HIP(hipGetLastError());
     dim3 rg((unsigned)((l + 63) / 64), (unsigned)(16 * nct));
     hipLaunchKernelGGL((k::slab_reduce_deep_kernel<T>), rg, dim3(256), 0, stream, (const T*)g.slab, g.slab_stride, (int)ngroups,
-                       out.p, out.ld, l, (int64_t)(16 * nct), scale_dev);
+                       out.p, out.ld, l, (int64_t)(16 * nct), scale_dev, run_if_);
     CORRLA_HIP(hipGetLastError());
     return true;
   }
@@ -1432,6 +1488,7 @@ class HipDev {
     a.slab_stride = (int64_t)out.ld * cb.cols_alloc;
     if (nsplit > 1) a.slab = (T*)alloc_bytes((size_t)nsplit * (size_t)a.slab_stride * sizeof(T));
     a.outer_blocks = (int)outer_tiles;
+    a.run_if = run_if_;
     a.vec_store = ((out.ld % 4) == 0 && ((uintptr_t)out.p % 16) == 0) ? 1 : 0;
     a.rotate = (!tn && !alias && a.tiles_per_split <= 32 && a.tiles_per_split > 1 && !env_int("CORRLA_GEMM_NO_ROTATE", 0)) ? 1 : 0;
     // Short reductions (A Z with n = 512: 8 tiles; Y R^-1: 2): a workgroup per outer tile spends a fifth of its life
@@ -1475,13 +1532,13 @@ class HipDev {
       dim3 rg((unsigned)((outer_n + 63) / 64), (unsigned)cb.cols_alloc);
       check_grid(rg);
       hipLaunchKernelGGL((k::slab_reduce_deep_kernel<T>), rg, dim3(256), 0, stream, (const T*)a.slab, a.slab_stride,
-                         nsplit, out.p, out.ld, outer_n, a.out_cols, scale_dev);
+                         nsplit, out.p, out.ld, outer_n, a.out_cols, scale_dev, run_if_);
       CORRLA_HIP(hipGetLastError());
     } else if (nsplit > 1) {
       dim3 rg((unsigned)((outer_n + 255) / 256), (unsigned)cb.cols_alloc);
       check_grid(rg);
       hipLaunchKernelGGL((k::slab_reduce_kernel<T>), rg, dim3(256), 0, stream, (const T*)a.slab, a.slab_stride, nsplit,
-                         out.p, out.ld, outer_n, a.out_cols, scale_dev);
+                         out.p, out.ld, outer_n, a.out_cols, scale_dev, run_if_);
       CORRLA_HIP(hipGetLastError());
     }
   }

@@ -129,6 +129,8 @@ struct GemmArgs {
   int tiles_per_split;
   int nsplit;
   int debug_flags;    // timing-only ablation (wrong results): 1 = no DMA after the first tile
+  const int* run_if;  // optional device word: the launch does nothing when it is 0 (conditional passes of the
+                      // device-side Cholesky-QR, driver.hpp: orthonormalize_device)
   int vec_store;      // out (and the slabs) are 16-byte aligned with out_ld % 4 == 0
   int rotate;         // gemm_nn: workgroup x walks the reduction tiles from tile x mod (tiles per split), wrapping
   int outer_blocks;   // outer tiles in all; workgroup x of gridDim.x takes x, x + gridDim.x, ... (persistent launches of
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
   constexpr int BIG = big_tile_bytes(MW);
   static_assert(!ALIAS || 16 * NT <= 64 * MW, "alias: the outer tile must hold every column");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (g.run_if && *g.run_if == 0) return;  // uniform over the grid
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row_first = (int64_t)blockIdx.x * outer_tile(MW);
@@ -526,6 +529,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
   constexpr int RBT = 64 * MW * (int)sizeof(T);  // bytes per row of the big tile (64*MW outer columns)
   constexpr int LPR = RBT / 16;                  // lanes per row in one DMA instruction (16..128)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (g.run_if && *g.run_if == 0) return;  // uniform over the grid
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t n_first = (int64_t)blockIdx.x * outer_tile(MW);
@@ -738,7 +742,8 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
 // out[col][i] = scale * sum_z slab[z][col][i], i < limit, col < ncols; fixed summation tree (deterministic)
 template <class T>
 __global__ void slab_reduce_kernel(const T* slab, int64_t slab_stride, int nsplit, T* out, int64_t ld, int64_t limit,
-                                   int64_t ncols, const T* scale) {
+                                   int64_t ncols, const T* scale, const int* run_if = nullptr) {
+  if (run_if && *run_if == 0) return;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t col = blockIdx.y;
   if (i >= limit || col >= ncols) return;
@@ -751,7 +756,9 @@ __global__ void slab_reduce_kernel(const T* slab, int64_t slab_stride, int nspli
 // many slabs, small output (the Gram matrices): 64 outputs x 4 slab groups per block, four loads in flight each
 template <class T>
 __global__ __launch_bounds__(256) void slab_reduce_deep_kernel(const T* slab, int64_t slab_stride, int nsplit, T* out,
-                                                               int64_t ld, int64_t limit, int64_t ncols, const T* scale) {
+                                                               int64_t ld, int64_t limit, int64_t ncols, const T* scale,
+                                                               const int* run_if = nullptr) {
+  if (run_if && *run_if == 0) return;
   __shared__ T part[4][64];
   const int li = threadIdx.x & 63, zg = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + li;
@@ -2184,9 +2191,34 @@ struct CholStatus {
   float gmax;
   long long clk, wall;  // shader-clock and 100 MHz wall-clock ticks spent in the elimination loop
 };
+// Robust form (rq.need_next != nullptr), used by the device-side Cholesky-QR that never asks the host:
+//  * the factorisation is that of G + shift_rel * max_i g_ii * I whenever the Gram is further than 0.25 from I (or
+//    always: shift_mode 1; never: shift_mode 2).  A shifted factor stays non-singular however ill-conditioned the
+//    sketch is, the product Y R_s^-1 keeps the span of Y and AMPLIFIES its weak directions by up to 1 / sqrt(shift_rel)
+//    relative to the strong ones -- they come from Y itself, not from the (squared) Gram -- so a few shifted passes
+//    unfold condition numbers up to 1 / eps like a Householder QR does (shifted CholeskyQR3, Fukaya et al. 2020);
+//  * a pivot that fails the test all the same (an exactly zero column, or a shift below the Gram's rounding error)
+//    is a NULL column instead of a failure: it is skipped, column j of R^-1 is zero (the applied product leaves a zero
+//    column that refill_null_kernel replaces by a random one) and null_mask[j] = 1;
+//  * need_next <- 1 when the product of this pass cannot be orthonormal to working precision yet (it was shifted, has
+//    null columns, or its Gram was further than 0.25 from I), else 0: the kernels of the next pass carry it as their
+//    run_if word;
+//  * run_if: the whole launch does nothing when *run_if == 0.
+struct CholRobust {
+  float shift_rel;
+  int shift_mode;  // 0: shift iff ||G - I||_max > 0.25, 1: always, 2: never
+  float null_excess;  // > 0 (shifted passes only): a column whose pivot exceeds the shift by less than null_excess * shift
+                      // -- it lies below the level one shifted pass can lift -- is a null column as well (in-loop
+                      // re-orthonormalisations: such directions are re-seeded at random rather than kept as noise)
+  int* need_next;
+  int* null_mask;  // r words
+  const int* run_if;
+};
 template <class T>
 __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g, int64_t ldg, int r, T piv_rel, T* m,
-                                                        int64_t ldm, CholStatus* st) {
+                                                        int64_t ldm, CholStatus* st, CholRobust rq = CholRobust{0.f, 0, 0.f, nullptr, nullptr, nullptr}) {
+  if (rq.run_if && *rq.run_if == 0) return;
+  const bool robust = rq.need_next != nullptr;
   // Register-resident Gaussian elimination of [G | I] in one sweep of r steps, one barrier per step.
   // Thread t owns the 4x4 tile (ti <= tk) of the upper triangle of G (v) and the same tile of W (w), where
   // W(x, y) = L^-1(y, x) for the unit-lower factor G = L U.  Step j: the owners of row j of the reduced G
@@ -2256,6 +2288,30 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
   }
   int fl = bad ? 3 : (!(g2 > 0.f) ? 2 : 0);
   float min_ratio = 1.f;
+  int nnull = 0;
+  if (robust && fl == 2) {
+    // the zero matrix: every column is null (M = 0, all of them are refilled)
+    for (int j = tid; j < r; j += blockDim.x) rq.null_mask[j] = 1;
+    if (own) {
+#pragma unroll
+      for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int i = i0 + aa, k = k0 + b;
+          if (i <= k && k < r) m[(int64_t)k * ldm + i] = (T)0;
+        }
+    }
+    if (tid == 0) {
+      *rq.need_next = 1;
+      st->fail = 0;
+      st->min_ratio = 0.f;
+      st->dev_i = d2;
+      st->gmax = 0.f;
+      st->clk = 0;
+      st->wall = 0;
+    }
+    return;
+  }
   const long long clk0 = clock64(), wall0 = wall_clock64();
   // G = I + E with a tiny E (the polishing pass of CholeskyQR2): (I + E)^(-1/2) = I - E/2 + 3E^2/8 - ..., and
   // 3 ||E||^2 / 8 is below eps / 4, so the symmetric first-order factor replaces the elimination (uniform branch).
@@ -2274,7 +2330,10 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
           }
         }
     }
+    if (robust)
+      for (int j = tid; j < r; j += blockDim.x) rq.null_mask[j] = 0;
     if (tid == 0) {
+      if (robust) *rq.need_next = 0;
       st->fail = 0;
       st->min_ratio = 1.f;
       st->dev_i = d2;
@@ -2283,6 +2342,16 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
       st->wall = 0;
     }
     return;
+  }
+  const bool shifted = robust && rq.shift_rel > 0.f && (rq.shift_mode == 1 || (rq.shift_mode == 0 && d2 > 0.25f));
+  const T sh = shifted ? (T)rq.shift_rel * (T)g2 : (T)0;
+  if (fl == 0 && shifted) {
+    // shifted factorisation: G + s I, s relative to the largest diagonal entry (the diagonal tiles own the diagonal)
+    if (own && ti == tk) {
+#pragma unroll
+      for (int aa = 0; aa < 4; ++aa)
+        if (i0 + aa < r) v[aa][aa] += sh;
+    }
   }
   if (fl == 0) {
     typedef T V4 __attribute__((ext_vector_type(4)));
@@ -2302,10 +2371,22 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
         const V4 rk4 = *(const V4*)&rb[k0];
         const V4 ri4 = *(const V4*)&rb[i0];
         const V4 ci4 = *(const V4*)&cb[i0];
-        if (!(d > piv_rel * g0) || !(g0 > (T)0)) {
-          fl = 1;  // uniform: every thread reads the same d
-          break;
+        if (!(d > piv_rel * g0) || !(g0 > (T)0) ||
+            (shifted && rq.null_excess > 0.f && !(d - sh > (T)rq.null_excess * sh))) {  // uniform: every thread reads the same d
+          if (!robust) {
+            fl = 1;
+            break;
+          }
+          // null column: no elimination step; its column of R^-1 is zero (dis = 0) and, the step being skipped, no
+          // other column of R^-1 receives a contribution from it
+          ++nnull;
+          if (tid == 0) {
+            dis[j] = (T)0;
+            rq.null_mask[j] = 1;
+          }
+          continue;
         }
+        if (robust && tid == 0) rq.null_mask[j] = 0;
         if (tid < 64) {
           min_ratio = fminf(min_ratio, (float)d * fast_rcp((float)g0));
           if (tid == 0) {
@@ -2363,13 +2444,27 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
       }
   }
   if (tid == 0) {
+    // a plain pass on a Gram within 0.05 of I leaves the product orthonormal to a few eps * sqrt(m)
+    if (robust) *rq.need_next = (nnull > 0 || d2 > 0.05f || shifted || fl != 0) ? 1 : 0;
     st->fail = fl;
-    st->min_ratio = min_ratio;
+    st->min_ratio = nnull > 0 ? 0.f : min_ratio;
     st->dev_i = d2;
     st->gmax = g2;
     st->clk = clk1 - clk0;
     st->wall = wall1 - wall0;
   }
+}
+// columns of y (m x l, column-major) marked in null_mask <- N(0, 1) / sqrt(m): the replacement of the null columns of
+// a device Cholesky-QR pass (any orthonormal completion serves, random_svd.rs:38,57 -- a Householder thin-Q returns
+// an arbitrary one as well); the following pass orthonormalises them against the rest.  grid = (blocks, l)
+template <class T>
+__global__ void refill_null_kernel(T* y, int64_t ld, int64_t m, int l, const int* null_mask, uint64_t seed, const int* run_if) {
+  if (run_if && *run_if == 0) return;
+  const int j = blockIdx.y;
+  if (j >= l || null_mask[j] == 0) return;
+  const T sc = (T)rsqrt((double)m);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x)
+    y[(int64_t)j * ld + i] = sc * normal_from_index<T>((uint64_t)(i * l + j), seed);
 }
 __host__ __device__ inline int chol_inv_threads(int r) {
   const int nt = (r + 3) / 4;

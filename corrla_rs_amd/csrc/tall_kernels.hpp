@@ -37,6 +37,7 @@ struct TallApplyArgs {
   int out_cols;    // columns of out that may be written
   const T* scale;  // optional device scalar
   int vec_store;   // out is 16-byte aligned with ld_o * sizeof(T) % 16 == 0
+  const int* run_if;  // optional device word: nothing happens when it is 0
 };
 
 // kdim <= 16 KTL, n2 <= 16 NCT.  grid: any (wave-strided over the row blocks), block 256
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void tall_apply_kernel(TallApplyArgs<T> g) {
   constexpr int VEC = MT<T>::VEC;
   constexpr int RB = 16 * VEC;  // rows per wave block
   constexpr int NKS = 4 * KTL;  // MFMA k-steps
+  if (g.run_if && *g.run_if == 0) return;
   const int lane = threadIdx.x & 63;
   const int fi = lane & 15, kq = lane >> 4;
   const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -135,6 +137,7 @@ struct TallGramArgs {
   int64_t slab_stride, out_ld;
   int64_t rows_per_group;  // multiple of the tile rows
   const T* zero;           // >= 16 bytes of zeros
+  const int* run_if;       // optional device word: nothing happens when it is 0
 };
 
 // rows per LDS tile: 512 bytes per column
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(256) void tall_gram_kernel(TallGramArgs<T> g) {
   static_assert(NCHUNK % 4 == 0, "pieces split evenly over the waves");
   constexpr int DPL = NCHUNK / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (g.run_if && *g.run_if == 0) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fi = lane & 15, kq = lane >> 4;

@@ -119,6 +119,7 @@ class EmuDev {
   template <class T>
   void gemm_nn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale) {
     if (x.rows != r.cols) throw Error(ST_EINVAL, "gemm_nn: inner dimensions differ");
+    if (skipped()) return;
     const ColBlocking cb = col_blocking(x.cols);
     if (cb.cols_alloc > x.cols_alloc || (!out.external && cb.cols_alloc > out.cols_alloc)) throw Error(ST_EINVAL, "emu: column padding");
     if (out.rows != r.rows) throw Error(ST_EINVAL, "emu: gemm output shape mismatch");
@@ -133,6 +134,7 @@ class EmuDev {
   template <class T>
   void gemm_tn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale) {
     if (x.rows != r.rows) throw Error(ST_EINVAL, "gemm_tn: inner dimensions differ");
+    if (skipped()) return;
     const ColBlocking cb = col_blocking(x.cols);
     if (cb.cols_alloc > x.cols_alloc || (!out.external && cb.cols_alloc > out.cols_alloc)) throw Error(ST_EINVAL, "emu: column padding");
     if (out.rows != r.cols) throw Error(ST_EINVAL, "emu: gemm output shape mismatch");
@@ -414,6 +416,141 @@ class EmuDev {
     st->fail = 0;
     st->min_ratio = (float)mr;
   }
+  // ---- device-robust Cholesky-QR (same contracts as HipDev; the host emulation reads the run_if word directly) ----
+  const int* run_if_ = nullptr;
+  bool skipped() const { return run_if_ && *run_if_ == 0; }
+  void set_run_if(const int* p) { run_if_ = p; }
+  int robust_passes_ = std::getenv("CORRLA_ROBUST_PASSES") ? std::atoi(std::getenv("CORRLA_ROBUST_PASSES")) : 2;
+  int robust_passes() const { return robust_passes_; }
+  void set_robust_passes(int n) { robust_passes_ = n; }
+  bool svd_more_sweeps() { return false; }
+  int* alloc_flags(int n) {
+    int* p = (int*)alloc_bytes(sizeof(int) * (size_t)std::max(n, 1));
+    std::memset(p, 0, sizeof(int) * (size_t)std::max(n, 1));
+    return p;
+  }
+  void* alloc_zeroed_bytes(size_t bytes) {
+    void* p = alloc_bytes(bytes);
+    std::memset(p, 0, bytes);
+    return p;
+  }
+  void read_flags(const int* dev_p, int n, int* host) { std::memcpy(host, dev_p, sizeof(int) * (size_t)n); }
+  template <class T>
+  bool device_qr_robust_fits(int64_t l) const {
+    return device_chol_fits<T>(l) && col_blocking(l).nblk == 1 && !std::getenv("CORRLA_EMU_NO_ROBUST_QR");
+  }
+  // k::chol_inv_kernel with a CholRobust record: shifted factorisation, failed pivots are null columns (zero columns of
+  // R^-1, the factor is that of the Gram with those rows and columns deleted), need_next / null_mask outputs
+  template <class T>
+  void chol_inv_robust(const Skinny<T>& g, int64_t r, T piv_rel, float shift_rel, int shift_mode, float null_excess,
+                       Skinny<T>& m_out, void* st_dev, int slot, int* need_next, int* null_mask) {
+    if (skipped()) return;
+    EmuCholStatus* st = (EmuCholStatus*)st_dev + slot;
+    std::vector<double> a((size_t)r * r);
+    double dv = 0.0, gm = 0.0;
+    bool finite = true;
+    for (int64_t j = 0; j < r; ++j)
+      for (int64_t i = 0; i < r; ++i) {
+        const double v = (double)g.p[j * g.ld + i];
+        a[j * r + i] = v;
+        finite = finite && std::isfinite(v);
+        dv = std::max(dv, std::fabs(v - (i == j ? 1.0 : 0.0)));
+        if (i == j) gm = std::max(gm, v);
+      }
+    std::memset(m_out.p, 0, (size_t)m_out.ld * m_out.cols_alloc * sizeof(T));
+    st->dev_i = (float)dv;
+    st->gmax = (float)gm;
+    st->min_ratio = 1.f;
+    st->fail = 0;
+    if (!finite) {
+      st->fail = 3;
+      *need_next = 1;
+      return;
+    }
+    if (!(gm > 0.0)) {  // the zero matrix: every column is null
+      for (int64_t j = 0; j < r; ++j) null_mask[j] = 1;
+      *need_next = 1;
+      return;
+    }
+    if (dv <= (sizeof(T) == 4 ? 2.0e-4 : 1.0e-8)) {
+      for (int64_t j = 0; j < r; ++j) {
+        null_mask[j] = 0;
+        for (int64_t i = 0; i < r; ++i)
+          m_out.p[j * m_out.ld + i] = (T)((i == j ? 1.0 : 0.0) - 0.5 * (a[j * r + i] - (i == j ? 1.0 : 0.0)));
+      }
+      *need_next = 0;
+      return;
+    }
+    std::vector<double> diag0((size_t)r);
+    for (int64_t j = 0; j < r; ++j) diag0[j] = a[j * r + j];
+    const bool shifted = shift_rel > 0.f && (shift_mode == 1 || (shift_mode == 0 && dv > 0.25));
+    const double sh = shifted ? (double)shift_rel * gm : 0.0;
+    for (int64_t j = 0; j < r; ++j) a[j * r + j] += sh;
+    // upper factor R (column-major: R(p, k) at rr[k * r + p]) over the surviving index set
+    std::vector<double> rr((size_t)r * r, 0.0);
+    int64_t nnull = 0;
+    double mr = 1.0;
+    for (int64_t j = 0; j < r; ++j) {
+      double d = a[j * r + j];
+      for (int64_t p = 0; p < j; ++p) d -= rr[j * r + p] * rr[j * r + p];
+      if (!(d > (double)piv_rel * diag0[j]) || !(diag0[j] > 0.0) || (shifted && null_excess > 0.f && d - sh <= (double)null_excess * sh)) {
+        null_mask[j] = 1;
+        ++nnull;
+        for (int64_t p = 0; p < j; ++p) rr[j * r + p] = 0.0;  // the column takes no part in anything
+        continue;
+      }
+      null_mask[j] = 0;
+      mr = std::min(mr, d / diag0[j]);
+      const double rjj = std::sqrt(d);
+      rr[j * r + j] = rjj;
+      for (int64_t k = j + 1; k < r; ++k) {
+        double v = a[k * r + j];
+        for (int64_t p = 0; p < j; ++p) v -= rr[j * r + p] * rr[k * r + p];
+        rr[k * r + j] = v / rjj;
+      }
+    }
+    // R^-1 on the surviving set (back substitution column by column); null rows and columns stay zero
+    std::vector<double> inv((size_t)r * r, 0.0);
+    for (int64_t c = 0; c < r; ++c) {
+      if (null_mask[c]) continue;
+      inv[c * r + c] = 1.0 / rr[c * r + c];
+      for (int64_t i = c - 1; i >= 0; --i) {
+        if (null_mask[i]) continue;
+        double v = 0.0;
+        for (int64_t p = i + 1; p <= c; ++p)
+          if (!null_mask[p]) v += rr[p * r + i] * inv[c * r + p];
+        inv[c * r + i] = -v / rr[i * r + i];
+      }
+    }
+    for (int64_t c = 0; c < r; ++c)
+      for (int64_t i = 0; i <= c; ++i) m_out.p[c * m_out.ld + i] = (T)inv[c * r + i];
+    st->min_ratio = nnull > 0 ? 0.f : (float)mr;
+    *need_next = (nnull > 0 || dv > 0.05 || shifted) ? 1 : 0;
+  }
+  template <class T>
+  void apply_inplace(Skinny<T>& y, int64_t l, const Skinny<T>& m) {
+    if (skipped()) return;
+    std::vector<double> row((size_t)l);
+    const ColBlocking cb = col_blocking(l);
+    for (int64_t i = 0; i < y.rows; ++i) {
+      for (int64_t c = 0; c < l; ++c) row[c] = (double)y.p[c * y.ld + i];
+      for (int64_t c = 0; c < cb.cols_alloc; ++c) {
+        double s = 0.0;
+        if (c < l)
+          for (int64_t kk = 0; kk < l; ++kk) s += row[kk] * (double)m.p[c * m.ld + kk];
+        y.p[c * y.ld + i] = (T)s;
+      }
+    }
+  }
+  template <class T>
+  void refill_null(Skinny<T>& y, int64_t l, const int* null_mask, uint64_t seed) {
+    if (skipped()) return;
+    const T sc = (T)(1.0 / std::sqrt((double)y.rows));
+    for (int64_t j = 0; j < l; ++j)
+      if (null_mask[j])
+        for (int64_t i = 0; i < y.rows; ++i) y.p[j * y.ld + i] = sc * normal_from_index<T>((uint64_t)(i * l + j), seed);
+  }
+
   void read_chol_status(const void* st_dev, int n, int* fail, float* min_ratio, float* dev_i) {
     const EmuCholStatus* st = (const EmuCholStatus*)st_dev;
     for (int i = 0; i < n; ++i) {

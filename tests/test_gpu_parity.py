@@ -1070,7 +1070,8 @@ def test_tall_thin_q_products_match_the_general_kernels_and_the_oracle(ctx, torc
     oracle, shared Omega."""
     import corrla_rs_amd as cr
     f32 = dtype == np.float32
-    s_tol, o_tol, r_tol = (2e-5, 5e-6, 1e-5) if f32 else (1e-12, 1e-13, 1e-11)
+    # orthonormality: a few eps * sqrt(rows) (the rounding level of an f32 Gram over 1.3e5 rows is ~4e-5)
+    s_tol, o_tol, r_tol = (2e-5, 2e-5, 1e-5) if f32 else (1e-12, 1e-13, 1e-11)
     rng = np.random.default_rng(m + l)
     p = min(5, l - 1)
     k = l - p

@@ -43,9 +43,9 @@ def test_row_sharded_world2_matches_single_rank():
             uo, so, vto = orc.random_svd(a.astype(dtype), k, q, p, omega=omega.astype(dtype))
             assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-5
             # exchanges per call: q + 1 all-reduces of the n x l factors (Z per iteration, B^T), one l x l Gram
-            # all-reduce per in-loop orthonormalisation (i > 2, single pass) and two for the final thin-Q
-            # (well-conditioned input).  No scalar all-reduce: the per-iteration rescale uses ||Z||_F, and Z is
-            # already replicated.
+            # all-reduce per in-loop orthonormalisation (i > 2, single pass) and two for the final thin-Q (well-conditioned
+            # input: the context never had to enqueue conditional passes, whose Gram all-reduces would be unconditional).
+            # No scalar all-reduce: the per-iteration rescale uses ||Z||_F, and Z is already replicated.
             n_ar = int(outs[0]["n_allreduce"])
             assert n_ar == (q + 1) + max(0, q - 3) + 2
 
