@@ -200,7 +200,6 @@ struct RsvdDriver {
   bool svd_needs_more_ = false;            // pending_clean: the core SVD ran out of enqueued sweeps
   int* flags_pool_ = nullptr;              // device words: need_next of every pass of every robust thin-Q of the call
   int flags_cap_ = 0, flags_used_ = 0;
-  int qr_site_ = 0;  // DEBUG bisect
   bool defer_status_ = false;
   bool optimistic_dirty_ = false;  // a pass of the optimistic run took the host-controlled loop: repeat the call
   void* st_pool_ = nullptr;
@@ -295,12 +294,12 @@ struct RsvdDriver {
     // pass AND keeps them more accurate (16384 x 16384 f32, sigma_i = 0.7^i: the 10th singular value to 1.6e-5 with
     // 16 eps, to 2.3e-4 with 1100 eps); a pivot that fails all the same only costs that column (null -> re-seeded).
     double shift_rel = eps0 * std::max(16.0, 0.25 * std::sqrt((double)std::max<int64_t>(y.rows, 1)));
-    if (const char* e = std::getenv("CORRLA_DBG_SHIFT_SCALE")) shift_rel *= std::atof(e);
+    if (const char* e = std::getenv("CORRLA_QR_SHIFT_SCALE")) shift_rel *= std::atof(e);  // experiments
     // in-loop: a direction whose residual is below the shift would leave the pass less than half normalised; such
     // half-lifted columns measurably hurt (DMDc snapshots: 7e-7 instead of 1e-14 in the 8th singular vector), so they
     // are re-seeded at random like the completion of the host-controlled path (which drops below 1e-2)
     float nullx = 1.f;
-    if (const char* e = std::getenv("CORRLA_DBG_NULLX")) nullx = (float)std::atof(e);
+    if (const char* e = std::getenv("CORRLA_QR_NULL_EXCESS")) nullx = (float)std::atof(e);  // experiments
     for (int pass = 0; pass < npass; ++pass) {
       dev.set_run_if(pass < always ? nullptr : need + pass - 1);
       Skinny<T> yv = y.view_cols(l);
@@ -334,9 +333,7 @@ struct RsvdDriver {
     int64_t r = l;
     // (sharded: the LOCAL row count says nothing -- and differs between ranks, which must all take the same branch;
     // a matrix with fewer global rows than l ends with need_next still set and repeats on the host-controlled path)
-    const char* dbg_mask = std::getenv("CORRLA_DBG_ROBUST_MASK");
-    const bool dbg_ok = !dbg_mask || (std::atoi(dbg_mask) & qr_site_);
-    if (dbg_ok && defer_status_ && (sharded || y.rows >= l) && flags_used_ + kRobustPasses <= flags_cap_ &&
+    if (defer_status_ && (sharded || y.rows >= l) && flags_used_ + kRobustPasses <= flags_cap_ &&
         dev.template device_qr_robust_fits<T>(l))
       return orthonormalize_device(y, sharded, rough, polish);
     if (dev.template device_chol_fits<T>(l)) {
@@ -593,7 +590,6 @@ struct RsvdDriver {
     for (int64_t i = i0; i < n_iter; ++i) {  // :35
       if (i > 2) {                          // :37-39
         phase(tm.power_ms, pt);
-        qr_site_ = 1;
         orthonormalize(y, y2, o.sharded, /*rough=*/true);
         phase(tm.qr_ms, pt);
       }
@@ -610,7 +606,6 @@ struct RsvdDriver {
       a_times(a, z, y, kNone);              // :47-51
     }
     phase(tm.power_ms, pt);
-    qr_site_ = 2;
     int64_t r = orthonormalize(y, y2, o.sharded);  // :57
     phase(tm.qr_ms, pt);
     return r;
@@ -703,6 +698,9 @@ struct RsvdDriver {
         continue;
       }
       if (p.rough && p.per_pass == 0) continue;  // one shifted pass in-loop: nothing to verify
+      if (std::getenv("CORRLA_DEBUG") && p.flag_slot < 0 && p.per_pass > 0)
+        std::fprintf(stderr, "[corrla] status record %d (%s): fail %d min_ratio %.3g dev_i %.3g\n", p.slot, p.is_svd ? "core SVD" : "Cholesky",
+                     fail[(size_t)p.slot], min_ratio[(size_t)p.slot], dev_i[(size_t)p.slot]);
       if (p.is_svd && fail[(size_t)p.slot] == 1) {  // not converged within the sweeps that were enqueued
         svd_needs_more_ = true;
         return false;
@@ -735,7 +733,6 @@ struct RsvdDriver {
     Skinny<T> qb = dev.template alloc_skinny<T>(a.nt, l);
     Skinny<T> qb2 = dev.template alloc_skinny<T>(a.nt, l);
     dev.copy_skinny(bt, qb);
-    qr_site_ = 4;
     orthonormalize(qb, qb2, false);
     phase(tm.qr_ms, pt);
     // The core is formed TRANSPOSED, C^T = B Qb = (Qb^T B^T)^T: C is the triangular factor R of B^T = Qb R (up to
@@ -764,7 +761,6 @@ struct RsvdDriver {
       // triplets move by less than their own uncertainty.  (The accumulated-rotation factor m2 is orthogonal by
       // construction.)  A rank-deficient core fails the pass and the call repeats on the host-controlled path.
       Skinny<T> m1b = dev.template alloc_skinny<T>(l, k);
-      qr_site_ = 8;
       orthonormalize_core(m1, m1b, false, /*rough=*/true, /*polish=*/true);
     }
     if (!defer_status_) {

@@ -699,11 +699,11 @@ class HipDev {
     return true;
   }
   template <class T, int NC>
-  void jmc_launch_step(int lanes, int np, int b, T* w, T* v, int nblocks, int step, int sweep, T tol, T tol_early, k::JmcCtl* ctl) {
+  void jmc_launch_step(int lanes, int np, int b, T* w, T* v, int nblocks, int step, int sweep, T tol, T tol_early, T floor2, k::JmcCtl* ctl) {
     const size_t lds = k::jmc_lds_bytes(NC, b, sizeof(T), lanes);
     const unsigned threads = (unsigned)((b * lanes + 63) / 64 * 64);
     hipLaunchKernelGGL((k::jmc_step_kernel<T, NC, 16>), dim3((unsigned)np), dim3(threads), lds, stream, w, v, b, nblocks, step,
-                       sweep, step == 0 ? 1 : 0, tol, tol_early, ctl);
+                       sweep, step == 0 ? 1 : 0, tol, tol_early, floor2, ctl);
   }
   // conv_status: device CholStatus record that receives the convergence verdict of the fixed number of sweeps
   // enqueued without any synchronisation (the caller checks it later); nullptr: sweeps are enqueued in groups and the
@@ -731,18 +731,19 @@ class HipDev {
     // orthonormal to 6e-5 only.  Running to a sweep without any rotation costs two more sweeps; the driver instead
     // re-orthonormalises that factor with one Cholesky-QR pass (a first-order (I + E)^-1/2 here), which is cheaper.
     const T tol_early = env_int("CORRLA_JACOBI_STRICT", 0) ? tol : (T)std::sqrt(eps);
+    const T floor2 = (T)((double)l * eps * eps);  // squared norm of a numerically zero column (see the kernel)
     auto enqueue_sweeps = [&](int s0, int s1) {
       for (int sw = s0; sw < s1; ++sw)
         for (int step = 0; step < nblocks - 1; ++step) switch (nc) {
-            case 1: jmc_launch_step<T, 1>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 2: jmc_launch_step<T, 2>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 3: jmc_launch_step<T, 3>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 4: jmc_launch_step<T, 4>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 5: jmc_launch_step<T, 5>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 6: jmc_launch_step<T, 6>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 7: jmc_launch_step<T, 7>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            case 8: jmc_launch_step<T, 8>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
-            default: jmc_launch_step<T, 9>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, ctl); break;
+            case 1: jmc_launch_step<T, 1>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, floor2, ctl); break;
+            case 2: jmc_launch_step<T, 2>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, floor2, ctl); break;
+            case 3: jmc_launch_step<T, 3>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, floor2, ctl); break;
+            case 4: jmc_launch_step<T, 4>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, floor2, ctl); break;
+            case 5: jmc_launch_step<T, 5>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, floor2, ctl); break;
+            case 6: jmc_launch_step<T, 6>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, floor2, ctl); break;
+            case 7: jmc_launch_step<T, 7>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, floor2, ctl); break;
+            case 8: jmc_launch_step<T, 8>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, floor2, ctl); break;
+            default: jmc_launch_step<T, 9>(lanes, np, b, wj, vj, nblocks, step, sw, tol, tol_early, floor2, ctl); break;
           }
       CORRLA_HIP(hipGetLastError());
     };
@@ -902,6 +903,7 @@ class HipDev {
     // quadratic convergence: a sweep that starts below sqrt(eps) ends below tol -- except for clustered singular
     // values, whose W / sigma factor the driver re-orthonormalises afterwards (see small_svd_mc)
     const T tol_early = env_int("CORRLA_JACOBI_STRICT", 0) ? tol : (T)std::sqrt(eps);
+    const T floor2 = (T)((double)l * eps * eps);  // squared norm of a numerically zero column (see the kernel)
     const bool v_lds = lds2 <= kLdsMax;
     const size_t lds = v_lds ? lds2 : lds1;
     // ring kernel: columns resident in registers (l <= 144)

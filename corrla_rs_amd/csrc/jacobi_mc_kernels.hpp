@@ -17,6 +17,11 @@
 // hang.  Squared column norms are recomputed at the start of every step and updated analytically in between
 // (a' = a - t g, b' = b + t g), so a round needs one dot product.
 //
+// Columns whose squared norm is below floor2 = l eps^2 (the core is pre-scaled to max |entry| in [1, 2)) are numerically
+// zero: every rotation against a large column re-injects rounding noise of their own size into them, so they would
+// never test orthogonal and the iteration would never end (a core with sigma_min / sigma_max below eps: 40 sweeps without
+// converging); they are left alone, like xGESVJ leaves columns below its underflow-scaled threshold.
+//
 // Convergence: every step ORs "rotated" / "some |cos| > tol_early" into per-sweep words; the launches of sweep S
 // return at once when sweep S-1 had no rotation above tol_early (quadratic convergence: that sweep was the last).
 // The host enqueues a fixed number of sweeps and never synchronises; jmc_finish_kernel reports whether the
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(1024) void jmc_init_kernel(const T* __restrict__ c,
 // LANES = 16 is what runs; 8 (f32 only: half the waves per block pair, twice the column per lane) measured slower.
 template <class T, int NC, int LANES>
 __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nblocks, int step, int sweep, int within,
-                                                        T tol, T tol_early, JmcCtl* ctl) {
+                                                        T tol, T tol_early, T floor2, JmcCtl* ctl) {
   typedef typename JmcVec<T>::v2 v2;
   constexpr int PITCH = jmc_pitch(NC, (int)sizeof(T), LANES);
   // converged in an earlier sweep (the flags were written by earlier launches): nothing to do
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
     for (int c = 1; c < NC; ++c) acc += x[c] * y[c];
     const T gg = jmc_sum<LANES>(acc[0] + acc[1]);
     T cs, sn, rel, t;
-    if (jacobi_rotation(na, nb, gg, tol, cs, sn, rel, t)) {  // uniform over the 16 lanes of a processor
+    if (na > floor2 && nb > floor2 && jacobi_rotation(na, nb, gg, tol, cs, sn, rel, t)) {  // uniform over the 16 lanes of a processor
       my_rot = 1;
       if (rel > tol_early) my_big = 1;
 #pragma unroll
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
         for (int c = 1; c < NC; ++c) acc += x[c] * y[c];
         const T gg = jmc_sum<LANES>(acc[0] + acc[1]);
         T cs, sn, rel, t;
-        if (jacobi_rotation(na, nb, gg, tol, cs, sn, rel, t)) {  // uniform over the lanes of a processor
+        if (na > floor2 && nb > floor2 && jacobi_rotation(na, nb, gg, tol, cs, sn, rel, t)) {  // uniform over the lanes of a processor
           my_rot = 1;
           if (rel > tol_early) my_big = 1;
 #pragma unroll

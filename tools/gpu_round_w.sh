@@ -13,4 +13,4 @@ for i in range(3):
     u, s, vt = ctx.rsvd(a, 128, 2, 10, seed=1)
     print("call", i, ctx.timings()["total_ms"], file=sys.stderr, flush=True)
 PY
-CORRLA_DEBUG=1 timeout -k 10 200 python /tmp/one_decay.py 2>&1 | grep -E "thin-Q|call" | cut -c1-420 | tee gpurun_out/r02/decay07_debug.txt
+CORRLA_DEBUG=1 timeout -k 10 200 python /tmp/one_decay.py 2>&1 | grep -E "thin-Q|call|status record|jacobi" | cut -c1-420 | tee gpurun_out/r02/decay07_debug.txt
