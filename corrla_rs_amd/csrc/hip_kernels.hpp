@@ -2214,8 +2214,13 @@ struct CholRobust {
   int* null_mask;  // r words
   const int* run_if;
 };
+// threads: one per 4 x 4 tile of the upper triangle.  f64 keeps 2 x 16 doubles of tile data per thread: at 1024 threads
+// (128 VGPRs) the compiler spilled 22 of them into the elimination loop (287 us at r = 138 against 62 us in f32), so
+// the f64 instantiation is bounded at 768 threads (170 VGPRs, r <= 152; wider f64 factors take the 2 x 2 blocked form)
 template <class T>
-__global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g, int64_t ldg, int r, T piv_rel, T* m,
+__host__ __device__ constexpr int chol_inv_max_threads() { return sizeof(T) == 8 ? 768 : 1024; }
+template <class T>
+__global__ __launch_bounds__(chol_inv_max_threads<T>()) void chol_inv_kernel(const T* __restrict__ g, int64_t ldg, int r, T piv_rel, T* m,
                                                         int64_t ldm, CholStatus* st, CholRobust rq = CholRobust{0.f, 0, 0.f, nullptr, nullptr, nullptr}) {
   if (rq.run_if && *rq.run_if == 0) return;
   const bool robust = rq.need_next != nullptr;
@@ -2379,14 +2384,12 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
           }
           // null column: no elimination step; its column of R^-1 is zero (dis = 0) and, the step being skipped, no
           // other column of R^-1 receives a contribution from it
+          // (dis[j] = 0 marks it: the mask goes to global memory after the loop -- a global store inside it would be
+          // waited for at every barrier)
           ++nnull;
-          if (tid == 0) {
-            dis[j] = (T)0;
-            rq.null_mask[j] = 1;
-          }
+          if (tid == 0) dis[j] = (T)0;
           continue;
         }
-        if (robust && tid == 0) rq.null_mask[j] = 0;
         if (tid < 64) {
           min_ratio = fminf(min_ratio, (float)d * fast_rcp((float)g0));
           if (tid == 0) {
@@ -2433,6 +2436,8 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const T* __restrict__ g,
   }
   const long long clk1 = clock64(), wall1 = wall_clock64();
   __syncthreads();
+  if (robust && fl == 0)
+    for (int j = tid; j < r; j += blockDim.x) rq.null_mask[j] = dis[j] == (T)0 ? 1 : 0;
   if (own) {
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa)
@@ -2474,8 +2479,7 @@ __host__ __device__ inline size_t chol_inv_lds_bytes(int r, size_t esz) {
   return (size_t)6 * (((size_t)r + 3) / 4 * 4) * esz + 32 * sizeof(float) + 64;
 }
 __host__ __device__ inline bool chol_inv_fits(int r, size_t esz) {
-  (void)esz;
-  return r >= 1 && chol_inv_threads(r) <= 1024;  // r <= 176
+  return r >= 1 && chol_inv_threads(r) <= (esz == 8 ? 768 : 1024);  // r <= 176 (f32) / 152 (f64)
 }
 
 // ---- (I + E)^(-1/2) by its Taylor series, for the polishing pass of the Cholesky-QR ---------------

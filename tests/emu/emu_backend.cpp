@@ -226,7 +226,7 @@ class EmuDev {
   };
   template <class T>
   bool device_chol_fits(int64_t l) const {
-    return l <= 176 && !std::getenv("CORRLA_EMU_NO_DEVICE_CHOL");
+    return l <= (sizeof(T) == 8 ? 152 : 176) && !std::getenv("CORRLA_EMU_NO_DEVICE_CHOL");
   }
   template <class T>
   bool device_chol_blocked_fits(int64_t l) const {
