@@ -198,6 +198,7 @@ struct RsvdDriver {
   static constexpr int kRobustPasses = 8;  // most passes a device-robust thin-Q enqueues (2 always, the rest conditional)
   bool robust_needs_more_ = false;         // pending_clean: a device-robust thin-Q ran out of enqueued passes
   bool svd_needs_more_ = false;            // pending_clean: the core SVD ran out of enqueued sweeps
+  bool svd_needs_v_ = false;               // pending_clean: the core SVD's W-only shortcut failed its verification
   int* flags_pool_ = nullptr;              // device words: need_next of every pass of every robust thin-Q of the call
   int flags_cap_ = 0, flags_used_ = 0;
   bool defer_status_ = false;
@@ -641,6 +642,7 @@ struct RsvdDriver {
         optimistic_dirty_ = false;
         robust_needs_more_ = false;
         svd_needs_more_ = false;
+        svd_needs_v_ = false;
         defer_status_ = true;
         try {
           random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
@@ -659,6 +661,8 @@ struct RsvdDriver {
           dev.set_robust_passes(std::min(kRobustPasses, 2 * std::max(2, dev.robust_passes())));
         } else if (svd_needs_more_ && dev.svd_more_sweeps()) {
           // the context enqueues more Jacobi sweeps from now on; repeat on the device
+        } else if (svd_needs_v_ && dev.svd_force_v()) {
+          // the context accumulates V in the sweeps from now on; repeat on the device
         } else {
           break;
         }
@@ -701,9 +705,16 @@ struct RsvdDriver {
       if (std::getenv("CORRLA_DEBUG") && p.flag_slot < 0 && p.per_pass > 0)
         std::fprintf(stderr, "[corrla] status record %d (%s): fail %d min_ratio %.3g dev_i %.3g\n", p.slot, p.is_svd ? "core SVD" : "Cholesky",
                      fail[(size_t)p.slot], min_ratio[(size_t)p.slot], dev_i[(size_t)p.slot]);
-      if (p.is_svd && fail[(size_t)p.slot] == 1) {  // not converged within the sweeps that were enqueued
-        svd_needs_more_ = true;
-        return false;
+      if (p.is_svd) {
+        if (fail[(size_t)p.slot] == 0) dev.svd_sweeps_used((int)dev_i[(size_t)p.slot]);
+        if (fail[(size_t)p.slot] == 1) {  // not converged within the sweeps that were enqueued
+          svd_needs_more_ = true;
+          return false;
+        }
+        if (fail[(size_t)p.slot] == 4) {  // the W-only shortcut was not valid for this core: accumulate V from now on
+          svd_needs_v_ = true;
+          return false;
+        }
       }
       for (int i = 0; i < p.npass * p.per_pass; ++i)
         if (fail[p.slot + i] != 0) return false;

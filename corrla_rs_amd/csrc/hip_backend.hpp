@@ -520,8 +520,18 @@ class HipDev {
   bool svd_more_sweeps() {
     if (jmc_extra_sweeps_ >= 24) return false;
     jmc_extra_sweeps_ += 8;
+    jmc_sweeps_hint_ = 0;
     return true;
   }
+  // the W-only shortcut of the block Jacobi failed its verification: accumulate V from now on (false: already does)
+  bool svd_force_v() {
+    if (jmc_force_v_) return false;
+    jmc_force_v_ = true;
+    return true;
+  }
+  // sweeps the last converged core SVD of this context used: the next call enqueues two more than that instead of the
+  // default (the sweeps enqueued beyond convergence are launches that only test a flag: 15 x 4.6 us at C2)
+  void svd_sweeps_used(int n) { jmc_sweeps_hint_ = std::max(jmc_sweeps_hint_ - 1, n); }
   int* alloc_flags(int n) { return (int*)alloc_zeroed(sizeof(int) * (size_t)std::max(n, 1)); }
   void* alloc_zeroed_bytes(size_t bytes) { return alloc_zeroed(bytes); }
   void read_flags(const int* dev_p, int n, int* host) {
@@ -721,7 +731,7 @@ class HipDev {
     k::CholStatus* st = conv_status ? (k::CholStatus*)conv_status : (k::CholStatus*)alloc_bytes(sizeof(k::CholStatus));
     // optimistic calls (conv_status given) may use the W-only mode when the core is well conditioned; the
     // host-controlled repeat always accumulates V
-    const int force_v = (conv_status == nullptr || env_int("CORRLA_JMC_FORCE_V", 0)) ? 1 : 0;
+    const int force_v = (conv_status == nullptr || jmc_force_v_ || env_int("CORRLA_JMC_FORCE_V", 0)) ? 1 : 0;
     hipLaunchKernelGGL((k::jmc_init_kernel<T>), dim3(1), dim3(1024), 0, stream, (const T*)c.p, c.ld, (int)l, wj, vj, rp,
                        ncols_pad, force_v, ctl);
     const double eps = (double)std::numeric_limits<T>::epsilon();
@@ -758,7 +768,8 @@ class HipDev {
       CORRLA_HIP(hipGetLastError());
     };
     if (conv_status) {
-      const int nsw = std::min(k::kJmcMaxSweeps, std::max(1, env_int("CORRLA_JMC_SWEEPS", sizeof(T) == 4 ? 10 : 13)) + jmc_extra_sweeps_);
+      const int nsw_default = std::max(1, env_int("CORRLA_JMC_SWEEPS", sizeof(T) == 4 ? 10 : 13));
+      const int nsw = std::min(k::kJmcMaxSweeps, (jmc_sweeps_hint_ > 0 ? std::min(nsw_default, jmc_sweeps_hint_ + 2) : nsw_default) + jmc_extra_sweeps_);
       enqueue_sweeps(0, nsw);
       finish(nsw);
       if (env_int("CORRLA_DEBUG", 0)) {
@@ -1214,7 +1225,8 @@ class HipDev {
   const int* run_if_ = nullptr;
   bool robust_qr_ = true;
   int robust_passes_ = 2;
-  int jmc_extra_sweeps_ = 0;
+  int jmc_extra_sweeps_ = 0, jmc_sweeps_hint_ = 0;
+  bool jmc_force_v_ = false;
   int64_t tall_min_rows_ = 65536;
 
   static void check_grid(const dim3& g) {

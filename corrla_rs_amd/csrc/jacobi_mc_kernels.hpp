@@ -476,14 +476,18 @@ __global__ __launch_bounds__(1024) void jmc_finish_kernel(const T* w, const T* v
     if (gl == 0) s_out[r] = (T)ldexp((double)sj, -sexp);
   }
   if (tid == 0 && st) {
-    int conv = 0;
-    for (int s = 0; s < nsweeps; ++s)
-      if (!(ctl->rot[s] && ctl->big[s])) conv = 1;
+    int conv = 0, used = nsweeps;
+    for (int s = nsweeps - 1; s >= 0; --s)
+      if (!(ctl->rot[s] && ctl->big[s])) {
+        conv = 1;
+        used = s + 1;  // sweeps that did work: the first one without a rotation above tol_early, and those before it
+      }
     // W-only mode is only valid for a well-conditioned core: verify the estimate that chose it against sigma
-    if (!with_v && !((float)sigma[order[k - 1]] * kJmcVerifyCond >= (float)sigma[order[0]])) conv = 0;
-    st->fail = ctl->bad ? 3 : (conv ? 0 : 1);
+    const bool wonly_bad = !with_v && !((float)sigma[order[k - 1]] * kJmcVerifyCond >= (float)sigma[order[0]]);
+    // fail: 0 converged, 1 ran out of sweeps, 3 non-finite input, 4 the W-only shortcut was not valid (repeat with V)
+    st->fail = ctl->bad ? 3 : (wonly_bad ? 4 : (conv ? 0 : 1));
     st->min_ratio = 1.f;
-    st->dev_i = 0.f;
+    st->dev_i = (float)used;  // read back as the hint for how many sweeps the next call of this context enqueues
     st->gmax = 1.f;
     st->clk = 0;
     st->wall = 0;

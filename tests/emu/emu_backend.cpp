@@ -424,6 +424,8 @@ class EmuDev {
   int robust_passes() const { return robust_passes_; }
   void set_robust_passes(int n) { robust_passes_ = n; }
   bool svd_more_sweeps() { return false; }
+  bool svd_force_v() { return false; }
+  void svd_sweeps_used(int) {}
   int* alloc_flags(int n) {
     int* p = (int*)alloc_bytes(sizeof(int) * (size_t)std::max(n, 1));
     std::memset(p, 0, sizeof(int) * (size_t)std::max(n, 1));
