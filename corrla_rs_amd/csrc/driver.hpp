@@ -192,6 +192,7 @@ struct RsvdDriver {
     bool rough;
     int per_pass;  // status records per pass: 1 (single factorisation) or 2 (2 x 2 blocked)
     void* st = nullptr;  // scratch status records of a device-robust thin-Q (diagnostics only)
+    int st_per_pass = 1;
     bool is_svd = false; // the convergence verdict of the core SVD's fixed number of sweeps
     int flag_slot = -1;  // >= 0: a device-robust Cholesky-QR (orthonormalize_device); clean iff flags[flag_slot + npass - 1] == 0
   };
@@ -275,9 +276,16 @@ struct RsvdDriver {
   // status records at the end of the call; a sketch that needs more passes than were enqueued repeats on the old path.
   // `polish`: the input is expected to be orthonormal already up to a small defect (the W / sigma factor of the core
   // SVD): no shift, and every pass after the first is conditional.
-  int64_t orthonormalize_device(Skinny<T>& y, bool sharded, bool rough, bool polish) {
+  // Wider sketches (two column blocks, l > 144) cannot run their products in place: the unconditional passes ping-pong
+  // between y and tmp as before, and the conditional ones come in PAIRS gated by the same word, so that a skipped pair
+  // leaves the data where the host expects it.  Factors wider than one chol_inv_kernel (l > 176 f32 / 152 f64) use the
+  // 2 x 2 blocked form: gram_inspect decides and adds the shift for the whole Gram, the two diagonal blocks are
+  // factorised by the robust kernel (null columns per block), combine_need forms the verdict of the pass.
+  int64_t orthonormalize_device(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough, bool polish) {
     const int64_t l = y.cols;
     PhaseTimer qt0;
+    const bool inplace = dev.qr_inplace_fits(l);
+    const bool single = dev.template device_chol_fits<T>(l);
     // how many passes are enqueued is a property of the CONTEXT: it starts at the two (polish: one) a well-conditioned
     // sketch needs -- no conditional launch at all -- and doubles (2 -> 4 -> 8) whenever a call ends with a thin-Q
     // still asking for more; the call is then repeated on the device with the higher count (random_svd_tall)
@@ -286,7 +294,9 @@ struct RsvdDriver {
     const int always = polish ? 1 : 2;
     int* need = flags_pool_ + flags_used_;
     int* null_mask = dev.alloc_flags((int)l);
-    void* st_scratch = dev.alloc_zeroed_bytes((size_t)npass * kStatusBytes);
+    int* need_blk = dev.alloc_flags(2);
+    void* st_scratch = dev.alloc_zeroed_bytes((size_t)2 * npass * kStatusBytes);
+    void* insp = single ? nullptr : dev.template alloc_inspect<T>();
     Skinny<T> gd = dev.template alloc_skinny<T>(l, l);
     Skinny<T> md = dev.template alloc_skinny<T>(l, l);
     const double eps0 = (double)std::numeric_limits<T>::epsilon();
@@ -301,20 +311,57 @@ struct RsvdDriver {
     // are re-seeded at random like the completion of the host-controlled path (which drops below 1e-2)
     float nullx = 1.f;
     if (const char* e = std::getenv("CORRLA_QR_NULL_EXCESS")) nullx = (float)std::atof(e);  // experiments
+    const int64_t n1 = single ? l : round_up((l + 1) / 2, (int64_t)4), n2 = l - n1;
+    T* minus_one = nullptr;
+    if (!single) {
+      minus_one = dev.template alloc_scalar<T>(1);
+      dev.fill_const(minus_one, (int64_t)1, (T)-1);
+    }
     for (int pass = 0; pass < npass; ++pass) {
-      dev.set_run_if(pass < always ? nullptr : need + pass - 1);
+      // gate: in place, the pass before; in pairs, the pass before the PAIR
+      const int gate = pass < always ? -1 : (inplace ? pass - 1 : always + ((pass - always) / 2) * 2 - 1);
+      dev.set_run_if(gate < 0 ? nullptr : need + gate);
       Skinny<T> yv = y.view_cols(l);
       dev.gemm_nn(as_rowmajor_transposed(y, l), yv, gd, kNone);
       if (sharded) dev.allreduce(gd.p, (size_t)gd.ld * (size_t)gd.cols_alloc);  // unconditional: ranks stay in step
+      const int shift_mode = polish ? 2 : (pass == 0 ? 1 : 0);
       // in-loop (rough): directions below the level one shifted pass can lift are re-seeded at random, like the
       // completion of the host-controlled path -- the next products with A pull the re-seeded columns back into range(A)
       // (final thin-Q: the first two passes only lift; what is still below the shift level in the third has no
       // independent information -- amplified rounding noise is not even linearly independent, it would be lifted and
       // crushed again for ever -- and is re-seeded too)
-      dev.chol_inv_robust(gd, l, (T)(4.0 * eps0), (float)shift_rel, polish ? 2 : (pass == 0 ? 1 : 0),
-                          ((rough && !polish) || (!polish && pass >= 2)) ? nullx : 0.f,
-                          md, st_scratch, pass, need + pass, null_mask);
-      dev.apply_inplace(y, l, md);
+      const float nx = ((rough && !polish) || (!polish && pass >= 2)) ? nullx : 0.f;
+      if (single) {
+        dev.chol_inv_robust(gd, l, (T)(4.0 * eps0), (float)shift_rel, shift_mode, nx, md, st_scratch, pass, need + pass, null_mask);
+      } else {
+        dev.gram_inspect(gd, l, (float)shift_rel, shift_mode, insp);
+        const void* shp = dev.template inspect_shift_ptr<T>(insp);
+        Skinny<T> g11 = dev.template alloc_skinny<T>(n1, n1), g12 = dev.template alloc_skinny<T>(n1, n2);
+        Skinny<T> g22 = dev.template alloc_skinny<T>(n2, n2), x11 = dev.template alloc_skinny<T>(n1, n1);
+        Skinny<T> x22 = dev.template alloc_skinny<T>(n2, n2), r12 = dev.template alloc_skinny<T>(n1, n2);
+        Skinny<T> t22 = dev.template alloc_skinny<T>(n2, n2), t12 = dev.template alloc_skinny<T>(n1, n2);
+        Skinny<T> x12 = dev.template alloc_skinny<T>(n1, n2);
+        dev.copy_block(gd, 0, 0, n1, n1, g11, 0, 0);
+        dev.copy_block(gd, 0, n1, n1, n2, g12, 0, 0);
+        dev.copy_block(gd, n1, n1, n2, n2, g22, 0, 0);
+        dev.chol_inv_robust(g11, n1, (T)(4.0 * eps0), 0.f, 2, nx, x11, st_scratch, 2 * pass, need_blk, null_mask, shp);
+        dev.gemm_nn(as_rowmajor_transposed(x11, n1), g12, r12, kNone);  // R12 = X11^T G12 (zero rows for null columns)
+        dev.gemm_nn(as_rowmajor_transposed(r12, n2), r12, t22, kNone);  // R12^T R12
+        dev.sub_inplace(g22, t22);                                      // Schur complement (carries the shift of G22)
+        dev.chol_inv_robust(g22, n2, (T)(4.0 * eps0), 0.f, 2, nx, x22, st_scratch, 2 * pass + 1, need_blk + 1, null_mask + n1, shp);
+        dev.gemm_tn(as_rowmajor_transposed(r12, n2), x22, t12, kNone);      // R12 X22
+        dev.gemm_tn(as_rowmajor_transposed(x11, n1), t12, x12, minus_one);  // -X11 R12 X22
+        dev.copy_block(x11, 0, 0, n1, n1, md, 0, 0);
+        dev.copy_block(x12, 0, 0, n1, n2, md, 0, n1);
+        dev.copy_block(x22, 0, 0, n2, n2, md, n1, n1);
+        dev.template combine_need<T>(need + pass, insp, need_blk, need_blk + 1);
+      }
+      if (inplace) {
+        dev.apply_inplace(y, l, md);
+      } else {
+        dev.gemm_tn(as_rowmajor_transposed(y, l), md, tmp, kNone);
+        std::swap(y.p, tmp.p);  // conditional passes come in pairs: a skipped pair swaps twice over untouched data
+      }
       // (a re-seeded column needs a following pass to be orthonormalised: none after the last one)
       if (pass + 1 < npass || npass == 1) dev.refill_null(y, l, null_mask, (uint64_t)(0x9e3779b97f4a7c15ull ^ (uint64_t)(977 * (flags_used_ + pass) + l)));
       if (pass < always) ++tm.qr_passes;  // the conditional ones are counted when the flags are read (pending_clean)
@@ -322,6 +369,7 @@ struct RsvdDriver {
     dev.set_run_if(nullptr);
     Pending pd{always, npass, rough, 0};
     pd.st = st_scratch;
+    pd.st_per_pass = single ? 1 : 2;
     pd.flag_slot = (rough && !polish) ? -1 : flags_used_;
     pending_.push_back(pd);
     flags_used_ += npass;
@@ -336,7 +384,7 @@ struct RsvdDriver {
     // a matrix with fewer global rows than l ends with need_next still set and repeats on the host-controlled path)
     if (defer_status_ && (sharded || y.rows >= l) && flags_used_ + kRobustPasses <= flags_cap_ &&
         dev.template device_qr_robust_fits<T>(l))
-      return orthonormalize_device(y, sharded, rough, polish);
+      return orthonormalize_device(y, tmp, sharded, rough, polish);
     if (dev.template device_chol_fits<T>(l)) {
       // Optimistic CholeskyQR2 entirely on the device: [Gram, Cholesky + inverse, apply] x2 are enqueued
       // back to back and the two status records are read once at the end.  Anything unusual (a failed
@@ -688,11 +736,12 @@ struct RsvdDriver {
         if (std::getenv("CORRLA_DEBUG")) {
           std::fprintf(stderr, "[corrla] device thin-Q: %d passes enqueued, need_next =", p.npass);
           for (int i = 0; i < p.npass; ++i) std::fprintf(stderr, " %d", flags[(size_t)p.flag_slot + i]);
-          std::vector<int> f2((size_t)p.npass);
-          std::vector<float> mr((size_t)p.npass), di((size_t)p.npass);
-          dev.read_chol_status(p.st, p.npass, f2.data(), mr.data(), di.data());
-          std::fprintf(stderr, "; ||G - I||_max / min pivot ratio per pass:");
-          for (int i = 0; i < p.npass; ++i) std::fprintf(stderr, " %.2g/%.2g", di[(size_t)i], mr[(size_t)i]);
+          const int nrec = p.npass * p.st_per_pass;
+          std::vector<int> f2((size_t)nrec);
+          std::vector<float> mr((size_t)nrec), di((size_t)nrec);
+          dev.read_chol_status(p.st, nrec, f2.data(), mr.data(), di.data());
+          std::fprintf(stderr, "; ||G - I||_max / min pivot ratio per factorisation:");
+          for (int i = 0; i < nrec; ++i) std::fprintf(stderr, " %.2g/%.2g", di[(size_t)i], mr[(size_t)i]);
           std::fprintf(stderr, "\n");
         }
         if (flags[(size_t)p.flag_slot + p.npass - 1] != 0) {

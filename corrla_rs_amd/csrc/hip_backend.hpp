@@ -540,12 +540,33 @@ class HipDev {
   }
   template <class T>
   bool device_qr_robust_fits(int64_t l) const {
-    return robust_qr_ && device_chol_fits<T>(l) && col_blocking(l).nblk == 1;
+    return robust_qr_ && (device_chol_fits<T>(l) || device_chol_blocked_fits<T>(l));
+  }
+  // one column block: the products of a pass may run in place (see apply_inplace)
+  bool qr_inplace_fits(int64_t l) const { return col_blocking(l).nblk == 1; }
+  // 2 x 2 blocked robust factorisation (l > 176 / 152): the whole Gram is inspected (shift decision, ||G - I||) and shifted
+  // once, the two diagonal-block factorisations take the shift from the record, combine_need forms the pass verdict
+  template <class T>
+  void* alloc_inspect() { return alloc_zeroed(sizeof(k::GramInspect<T>)); }
+  template <class T>
+  const void* inspect_shift_ptr(const void* insp) const { return &((const k::GramInspect<T>*)insp)->shift; }
+  template <class T>
+  void gram_inspect(Skinny<T>& g, int64_t l, float shift_rel, int shift_mode, void* insp) {
+    hipLaunchKernelGGL((k::gram_inspect_kernel<T>), dim3(1), dim3(1024), 0, stream, g.p, g.ld, (int)l, shift_rel, shift_mode,
+                       (k::GramInspect<T>*)insp, run_if_);
+    CORRLA_HIP(hipGetLastError());
+  }
+  template <class T>
+  void combine_need(int* need, const void* insp, const int* na, const int* nb) {
+    hipLaunchKernelGGL((k::combine_need_kernel<T>), dim3(1), dim3(1), 0, stream, need, (const k::GramInspect<T>*)insp, na, nb,
+                       run_if_);
+    CORRLA_HIP(hipGetLastError());
   }
   template <class T>
   void chol_inv_robust(const Skinny<T>& g, int64_t r, T piv_rel, float shift_rel, int shift_mode, float null_excess,
-                       Skinny<T>& m_out, void* st_dev, int slot, int* need_next, int* null_mask) {
-    k::CholRobust rb{shift_rel, shift_mode, null_excess, need_next, null_mask, run_if_};
+                       Skinny<T>& m_out, void* st_dev, int slot, int* need_next, int* null_mask,
+                       const void* abs_shift = nullptr) {
+    k::CholRobust rb{shift_rel, shift_mode, null_excess, need_next, null_mask, run_if_, abs_shift};
     hipLaunchKernelGGL((k::chol_inv_kernel<T>), dim3(1), dim3(k::chol_inv_threads((int)r)),
                        k::chol_inv_lds_bytes((int)r, sizeof(T)), stream, (const T*)g.p, g.ld, (int)r, piv_rel, m_out.p,
                        m_out.ld, (k::CholStatus*)st_dev + slot, rb);

@@ -2213,7 +2213,71 @@ struct CholRobust {
   int* need_next;
   int* null_mask;  // r words
   const int* run_if;
+  const void* abs_shift;  // optional (2 x 2 blocked factorisation): device scalar T = the shift gram_inspect_kernel has
+                          // ALREADY added to the diagonal of the whole Gram; decides `shifted` and feeds the null test
 };
+// what gram_inspect_kernel leaves for the blocked factorisation of one pass
+template <class T>
+struct GramInspect {
+  T shift;      // absolute shift added to the diagonal (0: none)
+  int shifted;
+  int bad;      // non-finite entries
+  float d2;     // ||G - I||_max before the shift
+  float gmax;
+};
+// One workgroup: inspects the l x l Gram (column-major, ld), decides the shift like the robust chol_inv_kernel does
+// (mode 0: iff ||G - I||_max > 0.25, 1: always, 2: never), adds it to the diagonal and leaves the record.
+template <class T>
+__global__ __launch_bounds__(1024) void gram_inspect_kernel(T* g, int64_t ld, int l, float shift_rel, int shift_mode,
+                                                            GramInspect<T>* out, const int* run_if) {
+  if (run_if && *run_if == 0) return;
+  __shared__ float rd[16], rg[16];
+  __shared__ int sbad;
+  const int tid = threadIdx.x;
+  if (tid == 0) sbad = 0;
+  float dv = 0.f, gm = 0.f;
+  int bad = 0;
+  for (int idx = tid; idx < l * l; idx += 1024) {
+    const int j = idx / l, i = idx - j * l;
+    const T x = g[(int64_t)j * ld + i];
+    if (!((float)fabs(x) < 3.0e38f)) bad = 1;
+    dv = fmaxf(dv, (float)fabs(x - (i == j ? (T)1 : (T)0)));
+    if (i == j) gm = fmaxf(gm, (float)x);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    dv = fmaxf(dv, __shfl_down(dv, off, 64));
+    gm = fmaxf(gm, __shfl_down(gm, off, 64));
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) {
+    rd[tid >> 6] = dv;
+    rg[tid >> 6] = gm;
+  }
+  if (bad) sbad = 1;
+  __syncthreads();
+  dv = 0.f;
+  gm = 0.f;
+  for (int i = 0; i < 16; ++i) {
+    dv = fmaxf(dv, rd[i]);
+    gm = fmaxf(gm, rg[i]);
+  }
+  const bool shifted = !sbad && gm > 0.f && shift_rel > 0.f && (shift_mode == 1 || (shift_mode == 0 && dv > 0.25f));
+  const T sh = shifted ? (T)shift_rel * (T)gm : (T)0;
+  if (shifted)
+    for (int i = tid; i < l; i += 1024) g[(int64_t)i * ld + i] += sh;
+  if (tid == 0) {
+    out->shift = sh;
+    out->shifted = shifted ? 1 : 0;
+    out->bad = sbad;
+    out->d2 = dv;
+    out->gmax = gm;
+  }
+}
+template <class T>
+__global__ void combine_need_kernel(int* need, const GramInspect<T>* insp, const int* na, const int* nb, const int* run_if) {
+  if (run_if && *run_if == 0) return;
+  *need = (insp->shifted || insp->bad || insp->d2 > 0.05f || *na || *nb) ? 1 : 0;
+}
 // threads: one per 4 x 4 tile of the upper triangle.  f64 keeps 2 x 16 doubles of tile data per thread: at 1024 threads
 // (128 VGPRs) the compiler spilled 22 of them into the elimination loop (287 us at r = 138 against 62 us in f32), so
 // the f64 instantiation is bounded at 768 threads (170 VGPRs, r <= 152; wider f64 factors take the 2 x 2 blocked form)
@@ -2221,7 +2285,7 @@ template <class T>
 __host__ __device__ constexpr int chol_inv_max_threads() { return sizeof(T) == 8 ? 768 : 1024; }
 template <class T>
 __global__ __launch_bounds__(chol_inv_max_threads<T>()) void chol_inv_kernel(const T* __restrict__ g, int64_t ldg, int r, T piv_rel, T* m,
-                                                        int64_t ldm, CholStatus* st, CholRobust rq = CholRobust{0.f, 0, 0.f, nullptr, nullptr, nullptr}) {
+                                                        int64_t ldm, CholStatus* st, CholRobust rq = CholRobust{0.f, 0, 0.f, nullptr, nullptr, nullptr, nullptr}) {
   if (rq.run_if && *rq.run_if == 0) return;
   const bool robust = rq.need_next != nullptr;
   // Register-resident Gaussian elimination of [G | I] in one sweep of r steps, one barrier per step.
@@ -2348,9 +2412,11 @@ __global__ __launch_bounds__(chol_inv_max_threads<T>()) void chol_inv_kernel(con
     }
     return;
   }
-  const bool shifted = robust && rq.shift_rel > 0.f && (rq.shift_mode == 1 || (rq.shift_mode == 0 && d2 > 0.25f));
-  const T sh = shifted ? (T)rq.shift_rel * (T)g2 : (T)0;
-  if (fl == 0 && shifted) {
+  const T pre_sh = rq.abs_shift ? *(const T*)rq.abs_shift : (T)0;  // blocked form: the shift is in the diagonal already
+  const bool shifted = rq.abs_shift ? pre_sh > (T)0
+                                    : (robust && rq.shift_rel > 0.f && (rq.shift_mode == 1 || (rq.shift_mode == 0 && d2 > 0.25f)));
+  const T sh = rq.abs_shift ? pre_sh : (shifted ? (T)rq.shift_rel * (T)g2 : (T)0);
+  if (fl == 0 && shifted && !rq.abs_shift) {
     // shifted factorisation: G + s I, s relative to the largest diagonal entry (the diagonal tiles own the diagonal)
     if (own && ti == tk) {
 #pragma unroll
@@ -2450,7 +2516,7 @@ __global__ __launch_bounds__(chol_inv_max_threads<T>()) void chol_inv_kernel(con
   }
   if (tid == 0) {
     // a plain pass on a Gram within 0.05 of I leaves the product orthonormal to a few eps * sqrt(m)
-    if (robust) *rq.need_next = (nnull > 0 || d2 > 0.05f || shifted || fl != 0) ? 1 : 0;
+    if (robust) *rq.need_next = (nnull > 0 || d2 > 0.05f || (shifted && !rq.abs_shift) || fl != 0) ? 1 : 0;
     st->fail = fl;
     st->min_ratio = nnull > 0 ? 0.f : min_ratio;
     st->dev_i = d2;

@@ -439,13 +439,53 @@ class EmuDev {
   void read_flags(const int* dev_p, int n, int* host) { std::memcpy(host, dev_p, sizeof(int) * (size_t)n); }
   template <class T>
   bool device_qr_robust_fits(int64_t l) const {
-    return device_chol_fits<T>(l) && col_blocking(l).nblk == 1 && !std::getenv("CORRLA_EMU_NO_ROBUST_QR");
+    return (device_chol_fits<T>(l) || device_chol_blocked_fits<T>(l)) && !std::getenv("CORRLA_EMU_NO_ROBUST_QR");
+  }
+  bool qr_inplace_fits(int64_t l) const { return col_blocking(l).nblk == 1; }
+  template <class T>
+  struct EmuInspect {
+    T shift;
+    int shifted, bad;
+    float d2, gmax;
+  };
+  template <class T>
+  void* alloc_inspect() { return alloc_zeroed_bytes(sizeof(EmuInspect<T>)); }
+  template <class T>
+  const void* inspect_shift_ptr(const void* insp) const { return &((const EmuInspect<T>*)insp)->shift; }
+  template <class T>
+  void gram_inspect(Skinny<T>& g, int64_t l, float shift_rel, int shift_mode, void* insp) {
+    if (skipped()) return;
+    EmuInspect<T>* o = (EmuInspect<T>*)insp;
+    double dv = 0.0, gm = 0.0;
+    bool finite = true;
+    for (int64_t j = 0; j < l; ++j)
+      for (int64_t i = 0; i < l; ++i) {
+        const double v = (double)g.p[j * g.ld + i];
+        finite = finite && std::isfinite(v);
+        dv = std::max(dv, std::fabs(v - (i == j ? 1.0 : 0.0)));
+        if (i == j) gm = std::max(gm, v);
+      }
+    const bool shifted = finite && gm > 0.0 && shift_rel > 0.f && (shift_mode == 1 || (shift_mode == 0 && dv > 0.25));
+    o->shift = shifted ? (T)((double)shift_rel * gm) : (T)0;
+    o->shifted = shifted ? 1 : 0;
+    o->bad = finite ? 0 : 1;
+    o->d2 = (float)dv;
+    o->gmax = (float)gm;
+    if (shifted)
+      for (int64_t i = 0; i < l; ++i) g.p[i * g.ld + i] += o->shift;
+  }
+  template <class T>
+  void combine_need(int* need, const void* insp, const int* na, const int* nb) {
+    if (skipped()) return;
+    const EmuInspect<T>* o = (const EmuInspect<T>*)insp;
+    *need = (o->shifted || o->bad || o->d2 > 0.05f || *na || *nb) ? 1 : 0;
   }
   // k::chol_inv_kernel with a CholRobust record: shifted factorisation, failed pivots are null columns (zero columns of
   // R^-1, the factor is that of the Gram with those rows and columns deleted), need_next / null_mask outputs
   template <class T>
   void chol_inv_robust(const Skinny<T>& g, int64_t r, T piv_rel, float shift_rel, int shift_mode, float null_excess,
-                       Skinny<T>& m_out, void* st_dev, int slot, int* need_next, int* null_mask) {
+                       Skinny<T>& m_out, void* st_dev, int slot, int* need_next, int* null_mask,
+                       const void* abs_shift = nullptr) {
     if (skipped()) return;
     EmuCholStatus* st = (EmuCholStatus*)st_dev + slot;
     std::vector<double> a((size_t)r * r);
@@ -485,9 +525,12 @@ class EmuDev {
     }
     std::vector<double> diag0((size_t)r);
     for (int64_t j = 0; j < r; ++j) diag0[j] = a[j * r + j];
-    const bool shifted = shift_rel > 0.f && (shift_mode == 1 || (shift_mode == 0 && dv > 0.25));
-    const double sh = shifted ? (double)shift_rel * gm : 0.0;
-    for (int64_t j = 0; j < r; ++j) a[j * r + j] += sh;
+    // blocked form: the shift is in the diagonal already (gram_inspect) and only feeds the null test
+    const double pre_sh = abs_shift ? (double)*(const T*)abs_shift : 0.0;
+    const bool shifted = abs_shift ? pre_sh > 0.0 : (shift_rel > 0.f && (shift_mode == 1 || (shift_mode == 0 && dv > 0.25)));
+    const double sh = abs_shift ? pre_sh : (shifted ? (double)shift_rel * gm : 0.0);
+    if (!abs_shift)
+      for (int64_t j = 0; j < r; ++j) a[j * r + j] += sh;
     // upper factor R (column-major: R(p, k) at rr[k * r + p]) over the surviving index set
     std::vector<double> rr((size_t)r * r, 0.0);
     int64_t nnull = 0;
@@ -527,7 +570,7 @@ class EmuDev {
     for (int64_t c = 0; c < r; ++c)
       for (int64_t i = 0; i <= c; ++i) m_out.p[c * m_out.ld + i] = (T)inv[c * r + i];
     st->min_ratio = nnull > 0 ? 0.f : (float)mr;
-    *need_next = (nnull > 0 || dv > 0.05 || shifted) ? 1 : 0;
+    *need_next = (nnull > 0 || dv > 0.05 || (shifted && !abs_shift)) ? 1 : 0;
   }
   template <class T>
   void apply_inplace(Skinny<T>& y, int64_t l, const Skinny<T>& m) {
