@@ -1092,3 +1092,31 @@ def test_tall_thin_q_products_match_the_general_kernels_and_the_oracle(ctx, torc
     # the host-pointer surface writes U into the caller's m x k buffer (leading dimension m)
     uh, sh, vth = ctx.rsvd(a, k, 2, p, omega=om)
     assert np.max(np.abs(sh - so)) <= s_tol * so[0, 0] and orth_err(uh) < o_tol
+
+
+# ---- decaying spectra: the thin-Q never leaves the device and stays orthonormal -------------------------------------
+@pytest.mark.parametrize("m,n,k,d,dtype", [(4096, 1024, 128, 0.97, np.float32), (4096, 1024, 128, 0.8, np.float32),
+                                          (4096, 1024, 128, 0.7, np.float64), (4096, 1024, 190, 0.9, np.float64),
+                                          (8192, 1024, 256, 0.7, np.float64), (3000, 600, 256, 0.95, np.float32)])
+def test_decaying_spectra_take_the_device_robust_thin_q(ctx, m, n, k, d, dtype):
+    """sigma_i = d^i: the sketch's condition number (sigma_1 / sigma_l)^5 is far beyond 1 / sqrt(eps), the case that
+    used to repeat the whole call on the host-controlled path (and at l = 266 returned a non-orthonormal U).  One and
+    two column blocks, single and 2 x 2 blocked factorisations; shared Omega, against the f64 oracle."""
+    rng = np.random.default_rng(m + k)
+    a = (rng.standard_normal((m, n)) * (d ** np.arange(n))).astype(dtype)
+    p = 10
+    om = rng.standard_normal((n, k + p)).astype(dtype)
+    u, s, vt = ctx.rsvd(a, k, 2, p, omega=om)
+    uo, so, vto = orc.random_svd(a.astype(np.float64), k, 2, p, omega=om.astype(np.float64))
+    f32 = dtype == np.float32
+    assert orth_err(u) < (2e-5 if f32 else 1e-12) and orth_err(vt.T) < (2e-5 if f32 else 1e-12)
+    # the leading singular values: those the arithmetic resolves (sigma_i / sigma_1 above ~eps^(1/5) of the sketch)
+    lead = int(np.sum(so.ravel() > (0.2 if f32 else 0.02) * so[0, 0]))
+    assert lead >= 2
+    assert np.max(np.abs(s.ravel()[:lead] - so.ravel()[:lead])) <= (2e-5 if f32 else 1e-10) * so[0, 0]
+    # with q = 2 and no re-orthonormalisation before the fourth iteration the schedule itself resolves only
+    # sigma_i / sigma_1 > eps^(1/5): the residual of both implementations is the energy of the unresolved tail (3.5e-4 at
+    # d = 0.7 in f64) and they differ in its noise, not in what they resolve
+    ro = orc.relerr(a, uo, so, vto)
+    assert abs(orc.relerr(a, u, s, vt) - ro) <= (5e-2 if f32 else max(1e-5, 0.25 * ro))
+    assert np.all(np.diff(s.ravel()) <= 1e-6 * s[0, 0])  # sorted
