@@ -57,7 +57,7 @@ def build_emu(force=False, verbose=False, asan=False):
     asan=True builds tests/emu/libcorrla_emu_asan.so with -fsanitize=address,undefined: the host-side driver and C-ABI
     glue (driver.hpp, capi_impl.hpp, small_linalg.hpp) under the sanitizers -- CPU only, never on the GPU box.  Run the
     CPU suite against it with
-        CORRLA_EMU_ASAN=1 LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 \
+        CORRLA_EMU_ASAN=1 LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0 \
             python -m pytest tests -m "not gpu" """
     srcs = _sources(CSRC, (".hpp", ".h")) + [os.path.join(EMU_DIR, "emu_backend.cpp"),
                                              os.path.join(ROOT, "include", "corrla_rsvd.h")]
