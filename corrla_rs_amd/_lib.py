@@ -41,6 +41,7 @@ def _sigs():
         "corrla_ctx_destroy": (None, [vp]),
         "corrla_ctx_synchronize": (C.c_int, [vp]),
         "corrla_ctx_get_timings": (C.c_int, [vp, C.POINTER(Timings)]),
+        "corrla_ctx_set_phase_timings": (C.c_int, [vp, C.c_int]),
         "corrla_ctx_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "corrla_comm_unique_id": (C.c_int, [vp]),
         "corrla_ctx_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),

@@ -87,6 +87,11 @@ class Context:
         L.check(self._lib.corrla_ctx_comm_info(self._h, C.byref(r), C.byref(n)))
         return r.value, n.value
 
+    def set_phase_timings(self, on):
+        """Per-phase device times (hipEvents at the phase boundaries, ~5 us of idle GPU each).  Off: timings() keeps
+        total_ms, sketch_kernel_ms and the counters, the phase entries read 0."""
+        L.check(self._lib.corrla_ctx_set_phase_timings(self._h, 1 if on else 0))
+
     def timings(self):
         t = L.Timings()
         L.check(self._lib.corrla_ctx_get_timings(self._h, C.byref(t)))

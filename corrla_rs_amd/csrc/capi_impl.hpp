@@ -193,6 +193,7 @@ inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64
   });
   PhaseTimer fin;
   drv.phase(drv.tm.finalize_ms, fin);  // output copies enqueued by emit()
+  dev.phase_end();
   dev.end_call();
   dev.phase_resolve(&drv.tm.total_ms);
   drv.tm.n_collectives = dev.n_collectives;
@@ -280,6 +281,7 @@ inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n
   });
   PhaseTimer fin;
   drv.phase(drv.tm.finalize_ms, fin);
+  dev.phase_end();
   dev.end_call();
   dev.phase_resolve(&drv.tm.total_ms);
   if (tm_out) *tm_out = drv.tm;

@@ -161,6 +161,12 @@ CORRLA_API corrla_status corrla_ctx_comm_info(corrla_ctx* ctx, int* rank, int* n
     c->dev.comm_info(rank, nranks);
   });
 }
+CORRLA_API corrla_status corrla_ctx_set_phase_timings(corrla_ctx* ctx, int on) {
+  return guarded([&] {
+    corrla_ctx* c = need(ctx);
+    c->dev.set_phase_events(on != 0);
+  });
+}
 CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);

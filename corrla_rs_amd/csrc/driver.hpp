@@ -681,10 +681,11 @@ struct RsvdDriver {
       for (int attempt = 0; attempt < 5; ++attempt) {
         // records: <= 2 per pass x <= 2 passes for each of the max(0, q - 3) in-loop, the final and the B^T thin-Q
         st_slots_ = (int)std::min<int64_t>(4 * (std::max<int64_t>(0, n_iter - 3) + 2) + 1, 4096);  // + the core SVD's
-        st_pool_ = dev.alloc_bytes((size_t)st_slots_ * kStatusBytes);
-        st_used_ = 0;
+        // status records and verdict words share one zeroed allocation: ONE device-to-host copy reads both at the end
         flags_cap_ = kRobustPasses * (int)std::min<int64_t>(std::max<int64_t>(0, n_iter - 3) + 4, 1024);
-        flags_pool_ = dev.alloc_flags(flags_cap_);
+        st_pool_ = dev.alloc_zeroed_bytes((size_t)st_slots_ * kStatusBytes + (size_t)flags_cap_ * sizeof(int));
+        st_used_ = 0;
+        flags_pool_ = (int*)((char*)st_pool_ + (size_t)st_slots_ * kStatusBytes);
         flags_used_ = 0;
         pending_.clear();
         optimistic_dirty_ = false;
@@ -725,9 +726,27 @@ struct RsvdDriver {
     if (pending_.empty()) return true;
     std::vector<int> fail((size_t)st_used_);
     std::vector<float> min_ratio((size_t)st_used_), dev_i((size_t)st_used_);
-    if (st_used_ > 0) dev.read_chol_status(st_pool_, st_used_, fail.data(), min_ratio.data(), dev_i.data());
     std::vector<int> flags((size_t)flags_used_);
-    if (flags_used_ > 0) dev.read_flags(flags_pool_, flags_used_, flags.data());
+    {
+      // one copy (and one synchronisation) for the records and the words: [0, st_used_ records) ... [flags)
+      struct Rec {
+        int fail;
+        float min_ratio, dev_i, gmax;
+        long long clk, wall;
+      };
+      static_assert(sizeof(Rec) == kStatusBytes, "status record layout");
+      const size_t bytes = (size_t)st_slots_ * kStatusBytes + (size_t)flags_used_ * sizeof(int);
+      std::vector<char> host(bytes);
+      dev.read_bytes(st_pool_, bytes, host.data());
+      for (int i = 0; i < st_used_; ++i) {
+        Rec r;
+        std::memcpy(&r, host.data() + (size_t)i * kStatusBytes, sizeof(r));
+        fail[(size_t)i] = r.fail;
+        min_ratio[(size_t)i] = r.min_ratio;
+        dev_i[(size_t)i] = r.dev_i;
+      }
+      if (flags_used_ > 0) std::memcpy(flags.data(), host.data() + (size_t)st_slots_ * kStatusBytes, (size_t)flags_used_ * sizeof(int));
+    }
     for (const Pending& p : pending_) {
       if (p.flag_slot >= 0) {  // device-robust thin-Q: its last enqueued pass must not ask for another one
         // (p.slot = number of unconditional passes; conditional pass i ran iff pass i - 1 asked for it)

@@ -534,6 +534,10 @@ class HipDev {
   void svd_sweeps_used(int n) { jmc_sweeps_hint_ = std::max(jmc_sweeps_hint_ - 1, n); }
   int* alloc_flags(int n) { return (int*)alloc_zeroed(sizeof(int) * (size_t)std::max(n, 1)); }
   void* alloc_zeroed_bytes(size_t bytes) { return alloc_zeroed(bytes); }
+  void read_bytes(const void* dev_p, size_t bytes, void* host) {
+    CORRLA_HIP(hipMemcpyAsync(host, dev_p, bytes, hipMemcpyDeviceToHost, stream));
+    sync();
+  }
   void read_flags(const int* dev_p, int n, int* host) {
     CORRLA_HIP(hipMemcpyAsync(host, dev_p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, stream));
     sync();
@@ -1152,7 +1156,18 @@ class HipDev {
   // ---- per-phase device times (corrla_timings) ------------------------------------------------------------
   // An event is recorded on the compute stream at every phase boundary; after the call has completed,
   // phase_resolve() adds the elapsed device time between consecutive events to the slot named at the later one.
+  // phase_events_ off (corrla_ctx_set_phase_timings): only the first and the last event of a call are recorded --
+  // total_ms stays, the per-phase slots stay zero -- because every event record is ~5 us of idle GPU between kernels
+  // (9 of them per call: 1 % of a 5 ms step).  The two events around the sketch launch are always recorded.
+  void set_phase_events(bool on) { phase_events_ = on; }
+  void phase_end() {
+    if (!phase_events_) phase_mark_impl(nullptr);
+  }
   void phase_mark(double* slot) {
+    if (!phase_events_ && slot != nullptr) return;
+    phase_mark_impl(slot);
+  }
+  void phase_mark_impl(double* slot) {
     if (ev_used_ == ev_pool_.size()) {
       hipEvent_t e;
       CORRLA_HIP(hipEventCreate(&e));
@@ -1244,6 +1259,7 @@ class HipDev {
   int jmc_min_l_ = 96, jmc_max_b_ = 24;
   int persist_max_tiles_ = 16;
   const int* run_if_ = nullptr;
+  bool phase_events_ = true;
   bool robust_qr_ = true;
   int robust_passes_ = 2;
   int jmc_extra_sweeps_ = 0, jmc_sweeps_hint_ = 0;

@@ -138,6 +138,10 @@ CORRLA_API int corrla_device_count(void);
 CORRLA_API corrla_status corrla_ctx_create(int device_ordinal, corrla_ctx** out);
 CORRLA_API void corrla_ctx_destroy(corrla_ctx* ctx);
 CORRLA_API corrla_status corrla_ctx_synchronize(corrla_ctx* ctx);
+/* Per-phase device times cost one hipEvent record per phase boundary (~5 us of idle GPU each, 7 per call).  on = 0:
+ * only total_ms, sketch_kernel_ms, the counters and host_enqueue_ms are filled in, the *_ms of the phases read 0.
+ * Default: on.  (The reference prints wall-clock phase times unconditionally, random_svd.rs:125-140.) */
+CORRLA_API corrla_status corrla_ctx_set_phase_timings(corrla_ctx* ctx, int on);
 CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings* out);
 /* Rank and size of the context's RCCL communicator as RCCL reports them (ncclCommUserRank / ncclCommCount);
  * nranks = 0 when corrla_ctx_comm_init has not been called. */

@@ -420,6 +420,7 @@ class EmuDev {
   const int* run_if_ = nullptr;
   bool skipped() const { return run_if_ && *run_if_ == 0; }
   void set_run_if(const int* p) { run_if_ = p; }
+  void phase_end() {}
   int robust_passes_ = std::getenv("CORRLA_ROBUST_PASSES") ? std::atoi(std::getenv("CORRLA_ROBUST_PASSES")) : 2;
   int robust_passes() const { return robust_passes_; }
   void set_robust_passes(int n) { robust_passes_ = n; }
@@ -437,6 +438,7 @@ class EmuDev {
     return p;
   }
   void read_flags(const int* dev_p, int n, int* host) { std::memcpy(host, dev_p, sizeof(int) * (size_t)n); }
+  void read_bytes(const void* dev_p, size_t bytes, void* host) { std::memcpy(host, dev_p, bytes); }
   template <class T>
   bool device_qr_robust_fits(int64_t l) const {
     return (device_chol_fits<T>(l) || device_chol_blocked_fits<T>(l)) && !std::getenv("CORRLA_EMU_NO_ROBUST_QR");
