@@ -362,8 +362,9 @@ struct RsvdDriver {
         dev.gemm_tn(as_rowmajor_transposed(y, l), md, tmp, kNone);
         std::swap(y.p, tmp.p);  // conditional passes come in pairs: a skipped pair swaps twice over untouched data
       }
-      // (a re-seeded column needs a following pass to be orthonormalised: none after the last one)
-      if (pass + 1 < npass || npass == 1) dev.refill_null(y, l, null_mask, (uint64_t)(0x9e3779b97f4a7c15ull ^ (uint64_t)(977 * (flags_used_ + pass) + l)));
+      // (a re-seeded column needs a following pass to be orthonormalised: none after the last one; in-loop, the next
+      // products with A and the next thin-Q take care of it)
+      if (pass + 1 < npass || (rough && !polish)) dev.refill_null(y, l, null_mask, (uint64_t)(0x9e3779b97f4a7c15ull ^ (uint64_t)(977 * (flags_used_ + pass) + l)));
       if (pass < always) ++tm.qr_passes;  // the conditional ones are counted when the flags are read (pending_clean)
     }
     dev.set_run_if(nullptr);
