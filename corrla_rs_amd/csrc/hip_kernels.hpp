@@ -937,15 +937,30 @@ __device__ __forceinline__ bool jacobi_rotation(float a, float b, float g, float
   float t;
   return jacobi_rotation(a, b, g, tol, cs, sn, rel, t);
 }
+// f64: the hardware reciprocal / reciprocal square root (~26 bits) refined by one Newton step each instead of the IEEE
+// division / square-root sequences (3 + 3 of them per rotation, ~2/3 of the dependent chain of a Jacobi round in f64).
+// The rotation only has to be orthogonal to rounding -- cs^2 + sn^2 = cs^2 (1 + t^2) is, whatever the last bits of t.
+__device__ __forceinline__ double jr_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  return y * (2.0 - x * y);
+}
+__device__ __forceinline__ double jr_rsq(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  return y * (1.5 - 0.5 * x * y * y);
+}
 __device__ __forceinline__ bool jacobi_rotation(double a, double b, double g, double tol, double& cs, double& sn,
                                                 double& rel, double& t) {
-  const double ab = sqrt(a) * sqrt(b);
-  rel = ab > 0.0 ? fabs(g) / ab : 0.0;
+  // |g| / sqrt(a b) without forming a * b (as in f32)
+  const double rs = (a > 0.0 && b > 0.0) ? jr_rsq(a) * jr_rsq(b) : 0.0;
+  rel = fabs(g) * rs;
   if (!(rel > tol)) return false;
-  const double zeta = (b - a) / (2.0 * g);
-  t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-  cs = 1.0 / sqrt(1.0 + t * t);
+  const double zeta = (b - a) * 0.5 * jr_rcp(g);
+  const double w = 1.0 + zeta * zeta;
+  const double den = fabs(zeta) + w * jr_rsq(w);  // sqrt(w)
+  t = copysign(jr_rcp(den), zeta);
+  cs = jr_rsq(1.0 + t * t);
   sn = cs * t;
+  if (!(fabs(sn) <= 1.0 && cs <= 1.0)) return false;  // subnormal-size columns / overflow of zeta: leave the pair alone
   return true;
 }
 __device__ __forceinline__ bool jacobi_rotation(double a, double b, double g, double tol, double& cs, double& sn,
