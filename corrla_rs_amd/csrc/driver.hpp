@@ -290,8 +290,13 @@ struct RsvdDriver {
     // sketch needs -- no conditional launch at all -- and doubles (2 -> 4 -> 8) whenever a call ends with a thin-Q
     // still asking for more; the call is then repeated on the device with the higher count (random_svd_tall)
     const int level = std::max(2, std::min(dev.robust_passes(), kRobustPasses));
-    const int npass = (rough && !polish) ? 1 : (polish ? (level <= 2 ? 1 : 3) : level);
-    const int always = polish ? 1 : 2;
+    // in-loop (rough, random_svd.rs:37-39): ONE shifted pass is enough whenever its pivots say the sketch was not too
+    // ill-conditioned for it (need_ratio); otherwise the same conditional chain as the final thin-Q lifts what can be
+    // lifted and re-seeds the rest (a context at level 2 has none enqueued: it escalates like for the final thin-Q)
+    const bool inloop = rough && !polish;
+    const int npass_even = level;  // 2, 4, 8
+    const int npass = inloop ? (level <= 2 ? 1 : npass_even - 1) : (polish ? (level <= 2 ? 1 : 3) : level);
+    const int always = (polish || inloop) ? 1 : 2;
     int* need = flags_pool_ + flags_used_;
     int* null_mask = dev.alloc_flags((int)l);
     int* need_blk = dev.alloc_flags(2);
@@ -330,9 +335,11 @@ struct RsvdDriver {
       // (final thin-Q: the first two passes only lift; what is still below the shift level in the third has no
       // independent information -- amplified rounding noise is not even linearly independent, it would be lifted and
       // crushed again for ever -- and is re-seeded too)
-      const float nx = ((rough && !polish) || (!polish && pass >= 2)) ? nullx : 0.f;
+      const float nx = (!polish && pass >= 2) ? nullx : 0.f;
+      const float need_ratio = (inloop && pass == 0) ? 1e-2f : 0.f;
       if (single) {
-        dev.chol_inv_robust(gd, l, (T)(4.0 * eps0), (float)shift_rel, shift_mode, nx, md, st_scratch, pass, need + pass, null_mask);
+        dev.chol_inv_robust(gd, l, (T)(4.0 * eps0), (float)shift_rel, shift_mode, nx, md, st_scratch, pass, need + pass, null_mask,
+                            nullptr, need_ratio);
       } else {
         dev.gram_inspect(gd, l, (float)shift_rel, shift_mode, insp);
         const void* shp = dev.template inspect_shift_ptr<T>(insp);
@@ -344,17 +351,18 @@ struct RsvdDriver {
         dev.copy_block(gd, 0, 0, n1, n1, g11, 0, 0);
         dev.copy_block(gd, 0, n1, n1, n2, g12, 0, 0);
         dev.copy_block(gd, n1, n1, n2, n2, g22, 0, 0);
-        dev.chol_inv_robust(g11, n1, (T)(4.0 * eps0), 0.f, 2, nx, x11, st_scratch, 2 * pass, need_blk, null_mask, shp);
+        dev.chol_inv_robust(g11, n1, (T)(4.0 * eps0), 0.f, 2, nx, x11, st_scratch, 2 * pass, need_blk, null_mask, shp, need_ratio);
         dev.gemm_nn(as_rowmajor_transposed(x11, n1), g12, r12, kNone);  // R12 = X11^T G12 (zero rows for null columns)
         dev.gemm_nn(as_rowmajor_transposed(r12, n2), r12, t22, kNone);  // R12^T R12
         dev.sub_inplace(g22, t22);                                      // Schur complement (carries the shift of G22)
-        dev.chol_inv_robust(g22, n2, (T)(4.0 * eps0), 0.f, 2, nx, x22, st_scratch, 2 * pass + 1, need_blk + 1, null_mask + n1, shp);
+        dev.chol_inv_robust(g22, n2, (T)(4.0 * eps0), 0.f, 2, nx, x22, st_scratch, 2 * pass + 1, need_blk + 1, null_mask + n1, shp,
+                            need_ratio);
         dev.gemm_tn(as_rowmajor_transposed(r12, n2), x22, t12, kNone);      // R12 X22
         dev.gemm_tn(as_rowmajor_transposed(x11, n1), t12, x12, minus_one);  // -X11 R12 X22
         dev.copy_block(x11, 0, 0, n1, n1, md, 0, 0);
         dev.copy_block(x12, 0, 0, n1, n2, md, 0, n1);
         dev.copy_block(x22, 0, 0, n2, n2, md, n1, n1);
-        dev.template combine_need<T>(need + pass, insp, need_blk, need_blk + 1);
+        dev.template combine_need<T>(need + pass, need_ratio > 0.f ? nullptr : insp, need_blk, need_blk + 1);
       }
       if (inplace) {
         dev.apply_inplace(y, l, md);
@@ -364,14 +372,16 @@ struct RsvdDriver {
       }
       // (a re-seeded column needs a following pass to be orthonormalised: none after the last one; in-loop, the next
       // products with A and the next thin-Q take care of it)
-      if (pass + 1 < npass || (rough && !polish)) dev.refill_null(y, l, null_mask, (uint64_t)(0x9e3779b97f4a7c15ull ^ (uint64_t)(977 * (flags_used_ + pass) + l)));
+      if (pass + 1 < npass || inloop) dev.refill_null(y, l, null_mask, (uint64_t)(0x9e3779b97f4a7c15ull ^ (uint64_t)(977 * (flags_used_ + pass) + l)));
       if (pass < always) ++tm.qr_passes;  // the conditional ones are counted when the flags are read (pending_clean)
     }
     dev.set_run_if(nullptr);
     Pending pd{always, npass, rough, 0};
     pd.st = st_scratch;
     pd.st_per_pass = single ? 1 : 2;
-    pd.flag_slot = (rough && !polish) ? -1 : flags_used_;
+    // in-loop: only the single pass of a level-2 context is verified (so that the context escalates); with a conditional
+    // chain enqueued the in-loop thin-Q is best effort -- it only has to keep the sketch well conditioned
+    pd.flag_slot = (inloop && npass > 1) ? -1 : flags_used_;
     pending_.push_back(pd);
     flags_used_ += npass;
     subphase(tm.qr_gram_ms, qt0);

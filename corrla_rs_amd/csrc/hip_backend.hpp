@@ -569,8 +569,8 @@ class HipDev {
   template <class T>
   void chol_inv_robust(const Skinny<T>& g, int64_t r, T piv_rel, float shift_rel, int shift_mode, float null_excess,
                        Skinny<T>& m_out, void* st_dev, int slot, int* need_next, int* null_mask,
-                       const void* abs_shift = nullptr) {
-    k::CholRobust rb{shift_rel, shift_mode, null_excess, need_next, null_mask, run_if_, abs_shift};
+                       const void* abs_shift = nullptr, float need_ratio = 0.f) {
+    k::CholRobust rb{shift_rel, shift_mode, null_excess, need_next, null_mask, run_if_, need_ratio, abs_shift};
     hipLaunchKernelGGL((k::chol_inv_kernel<T>), dim3(1), dim3(k::chol_inv_threads((int)r)),
                        k::chol_inv_lds_bytes((int)r, sizeof(T)), stream, (const T*)g.p, g.ld, (int)r, piv_rel, m_out.p,
                        m_out.ld, (k::CholStatus*)st_dev + slot, rb);

@@ -2228,6 +2228,8 @@ struct CholRobust {
   int* need_next;
   int* null_mask;  // r words
   const int* run_if;
+  float need_ratio;  // > 0 (the single pass of an in-loop thin-Q): need_next <- null columns or a pivot ratio d_j / g_jj below
+                     // this, i.e. the sketch was too ill-conditioned for one shifted pass to tame; 0: the standard rule
   const void* abs_shift;  // optional (2 x 2 blocked factorisation): device scalar T = the shift gram_inspect_kernel has
                           // ALREADY added to the diagonal of the whole Gram; decides `shifted` and feeds the null test
 };
@@ -2291,7 +2293,8 @@ __global__ __launch_bounds__(1024) void gram_inspect_kernel(T* g, int64_t ld, in
 template <class T>
 __global__ void combine_need_kernel(int* need, const GramInspect<T>* insp, const int* na, const int* nb, const int* run_if) {
   if (run_if && *run_if == 0) return;
-  *need = (insp->shifted || insp->bad || insp->d2 > 0.05f || *na || *nb) ? 1 : 0;
+  // insp == nullptr (the single pass of an in-loop thin-Q): the verdict is that of the two block factorisations alone
+  *need = ((insp && (insp->shifted || insp->bad || insp->d2 > 0.05f)) || *na || *nb) ? 1 : 0;
 }
 // threads: one per 4 x 4 tile of the upper triangle.  f64 keeps 2 x 16 doubles of tile data per thread: at 1024 threads
 // (128 VGPRs) the compiler spilled 22 of them into the elimination loop (287 us at r = 138 against 62 us in f32), so
@@ -2300,7 +2303,7 @@ template <class T>
 __host__ __device__ constexpr int chol_inv_max_threads() { return sizeof(T) == 8 ? 768 : 1024; }
 template <class T>
 __global__ __launch_bounds__(chol_inv_max_threads<T>()) void chol_inv_kernel(const T* __restrict__ g, int64_t ldg, int r, T piv_rel, T* m,
-                                                        int64_t ldm, CholStatus* st, CholRobust rq = CholRobust{0.f, 0, 0.f, nullptr, nullptr, nullptr, nullptr}) {
+                                                        int64_t ldm, CholStatus* st, CholRobust rq = CholRobust{0.f, 0, 0.f, nullptr, nullptr, nullptr, 0.f, nullptr}) {
   if (rq.run_if && *rq.run_if == 0) return;
   const bool robust = rq.need_next != nullptr;
   // Register-resident Gaussian elimination of [G | I] in one sweep of r steps, one barrier per step.
@@ -2531,7 +2534,12 @@ __global__ __launch_bounds__(chol_inv_max_threads<T>()) void chol_inv_kernel(con
   }
   if (tid == 0) {
     // a plain pass on a Gram within 0.05 of I leaves the product orthonormal to a few eps * sqrt(m)
-    if (robust) *rq.need_next = (nnull > 0 || d2 > 0.05f || (shifted && !rq.abs_shift) || fl != 0) ? 1 : 0;
+    if (robust) {
+      if (rq.need_ratio > 0.f)
+        *rq.need_next = (nnull > 0 || min_ratio < rq.need_ratio || fl != 0) ? 1 : 0;
+      else
+        *rq.need_next = (nnull > 0 || d2 > 0.05f || (shifted && !rq.abs_shift) || fl != 0) ? 1 : 0;
+    }
     st->fail = fl;
     st->min_ratio = nnull > 0 ? 0.f : min_ratio;
     st->dev_i = d2;

@@ -480,14 +480,14 @@ class EmuDev {
   void combine_need(int* need, const void* insp, const int* na, const int* nb) {
     if (skipped()) return;
     const EmuInspect<T>* o = (const EmuInspect<T>*)insp;
-    *need = (o->shifted || o->bad || o->d2 > 0.05f || *na || *nb) ? 1 : 0;
+    *need = ((o && (o->shifted || o->bad || o->d2 > 0.05f)) || *na || *nb) ? 1 : 0;
   }
   // k::chol_inv_kernel with a CholRobust record: shifted factorisation, failed pivots are null columns (zero columns of
   // R^-1, the factor is that of the Gram with those rows and columns deleted), need_next / null_mask outputs
   template <class T>
   void chol_inv_robust(const Skinny<T>& g, int64_t r, T piv_rel, float shift_rel, int shift_mode, float null_excess,
                        Skinny<T>& m_out, void* st_dev, int slot, int* need_next, int* null_mask,
-                       const void* abs_shift = nullptr) {
+                       const void* abs_shift = nullptr, float need_ratio = 0.f) {
     if (skipped()) return;
     EmuCholStatus* st = (EmuCholStatus*)st_dev + slot;
     std::vector<double> a((size_t)r * r);
@@ -572,7 +572,10 @@ class EmuDev {
     for (int64_t c = 0; c < r; ++c)
       for (int64_t i = 0; i <= c; ++i) m_out.p[c * m_out.ld + i] = (T)inv[c * r + i];
     st->min_ratio = nnull > 0 ? 0.f : (float)mr;
-    *need_next = (nnull > 0 || dv > 0.05 || (shifted && !abs_shift)) ? 1 : 0;
+    if (need_ratio > 0.f)
+      *need_next = (nnull > 0 || mr < (double)need_ratio) ? 1 : 0;
+    else
+      *need_next = (nnull > 0 || dv > 0.05 || (shifted && !abs_shift)) ? 1 : 0;
   }
   template <class T>
   void apply_inplace(Skinny<T>& y, int64_t l, const Skinny<T>& m) {
