@@ -67,8 +67,12 @@ __global__ __launch_bounds__(256) void tall_apply_kernel(TallApplyArgs<T> g) {
     }
   const T sc = g.scale ? *g.scale : (T)1;
 
-  // lane (p = fi, cq = kq): rows r0 + VEC p .. + VEC - 1 of column 4 j + cq
-  const T* ybase = g.y + (int64_t)kq * g.ld_y + VEC * fi;
+  // lane (p = fi, cq = kq): the VEC rows of piece perm(p) of column 4 j + cq.  MFMA tile row i may stand for any matrix
+  // row as long as loads and stores agree: f32 uses piece perm(i) = 4 (i % 4) + i / 4, so that the four lanes (rg) that
+  // hold D rows 4 rg + jp store the ADJACENT 16-byte pieces 4 jp + rg -- 64 contiguous bytes per column and store
+  // instruction instead of four isolated 16-byte pieces (f64 D rows are rg + 4 jp: adjacent already)
+  auto piece = [](int i) { return sizeof(T) == 4 ? 4 * (i & 3) + (i >> 2) : i; };
+  const T* ybase = g.y + (int64_t)kq * g.ld_y + VEC * piece(fi);
   const int64_t jstride = 4 * g.ld_y;
   auto load = [&](vec_t (&v)[NKS], int64_t blk) {
     const T* src = ybase + blk * RB;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void tall_apply_kernel(TallApplyArgs<T> g) {
         T* dst = g.out + (int64_t)col * g.ld_o;
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-          const int64_t row = blk * RB + VEC * MT<T>::drow(lane, jp);
+          const int64_t row = blk * RB + VEC * piece(MT<T>::drow(lane, jp));
           vec_t w;
 #pragma unroll
           for (int e = 0; e < VEC; ++e) w[e] = acc[e][ct][jp] * sc;
