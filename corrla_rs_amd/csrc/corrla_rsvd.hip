@@ -259,9 +259,9 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     if (!(n_pts > need_pts && n_nbrs > need_pts))
       throw Error(ST_EINVAL, "n_pts and n_nbrs must exceed k + 1 (order 1) / k (k + 3) / 2 (order 2)");
     if (n_nbrs > n_pts) throw Error(ST_EINVAL, "n_nbrs exceeds the number of support points");
-    if (n_nbrs > k::kGradMaxNbr) throw Error(ST_EINVAL, "more than 160 neighbours are not supported");
-    const int P = est_order == 1 ? (int)kf + 1 : (int)(kf + kf * (kf + 1) / 2 + 1);
-    if (P > k::kGradMaxCols) throw Error(ST_EINVAL, "the design matrix would have more than 66 columns (order 2 needs k <= 10)");
+    if (n_nbrs > k::kGradMaxNbr) throw Error(ST_EINVAL, "more than 512 neighbours are not supported");
+    if (k::grad_fit_lds_bytes((int)kf, (int)n_nbrs, est_order) > (size_t)160 * 1024)
+      throw Error(ST_EINVAL, "the neighbours and normal equations of one query do not fit in 160 KiB of LDS (order 2 needs k <= 14)");
     if (ldg < kf) throw Error(ST_EINVAL, "ldg < k");
     if (n_pts > 0x7fffffff || n_q * n_nbrs > ((int64_t)1 << 40)) throw Error(ST_EINVAL, "point set too large");
     locked_call(c, [&] {

@@ -26,8 +26,10 @@ namespace corrla {
 namespace k {
 
 constexpr int kGradMaxDim = 64;    // features k
-constexpr int kGradMaxNbr = 160;   // neighbours per query
-constexpr int kGradMaxCols = 66;   // design-matrix columns: k + 1 (order 1), k + k (k + 1) / 2 + 1 (order 2)
+constexpr int kGradMaxNbr = 512;   // neighbours per query (register arrays of the list insertion; LDS is checked per call)
+// design-matrix columns: k + 1 (order 1), k + k (k + 1) / 2 + 1 (order 2); no fixed cap -- the normal equations of a
+// query live in LDS next to its neighbours, so the bound is grad_fit_lds_bytes(k, n_nbrs, order) <= 160 KiB (order 2:
+// k <= 14 with the fewest neighbours the fit needs)
 constexpr int kKnnQueriesPerWave = 4, kKnnWaves = 4, kKnnQueries = kKnnQueriesPerWave * kKnnWaves;
 
 // xt (k x ldt, dimension-major) <- x (n x k, row-major)

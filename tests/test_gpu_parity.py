@@ -810,7 +810,8 @@ def _as_samples(cov, n, seed):
     return aso.sample_mv_normal(cov, n, np.random.default_rng(seed))
 
 
-@pytest.mark.parametrize("case", ["lin_k6", "lin_k64", "quad_k2", "quad_k3", "quad_k9", "quad_k10"])
+@pytest.mark.parametrize("case", ["lin_k6", "lin_k64", "quad_k2", "quad_k3", "quad_k9", "quad_k10", "quad_k12", "quad_k14",
+                                  "lin_k20"])
 def test_grad_mat_matches_the_oracle(ctx, case):
     """Exact nearest neighbours + local least-squares fits on the GPU against the numpy restatement: same neighbour
     sets (ties -> lower index), gradients equal to rounding (order 2: the oracle follows the reference's forward
@@ -819,8 +820,12 @@ def test_grad_mat_matches_the_oracle(ctx, case):
     rng = np.random.default_rng(len(case))
     order = 1 if case.startswith("lin") else 2
     k = int(case.split("k")[1])
-    n = {"lin_k6": 500, "lin_k64": 900, "quad_k2": 100, "quad_k3": 100, "quad_k9": 700, "quad_k10": 900}[case]
-    n_nbrs = {"lin_k6": 12, "lin_k64": 90, "quad_k2": 14, "quad_k3": 14, "quad_k9": 80, "quad_k10": 100}[case]
+    n = {"lin_k6": 500, "lin_k64": 900, "quad_k2": 100, "quad_k3": 100, "quad_k9": 700, "quad_k10": 900, "quad_k12": 1200,
+         "quad_k14": 1500, "lin_k20": 2000}[case]
+    # (quad_k12 / quad_k14: 91 / 120 design columns, lin_k20: 400 neighbours -- beyond the 66 columns / 160 neighbours of
+    # round 1; the bound is one query's LDS footprint now)
+    n_nbrs = {"lin_k6": 12, "lin_k64": 90, "quad_k2": 14, "quad_k3": 14, "quad_k9": 80, "quad_k10": 100, "quad_k12": 130,
+              "quad_k14": 150, "lin_k20": 400}[case]
     x = rng.standard_normal((n, k)) + 1.5
     w = rng.standard_normal(k)
     y = np.sin(x @ w * 0.3) + 0.1 * (x ** 2).sum(axis=1) - 4.0
