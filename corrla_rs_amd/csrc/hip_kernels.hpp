@@ -914,6 +914,13 @@ __device__ __forceinline__ double group_sum(double x) {
   for (int msk = 1; msk < G; msk <<= 1) x += __shfl_xor(x, msk, G);
   return x;
 }
+// sqrt of a squared column norm for the final ranking of the Jacobi kernels: a non-finite value (non-finite input, reported
+// through the status word) becomes 0, because comparisons with NaN are all false -- ranks would collide and the order
+// table would keep uninitialised entries, i.e. wild column indices in the output loop
+template <class T>
+__device__ __forceinline__ T jacobi_safe_sigma(T a) {
+  return (a >= (T)0 && a < (T)3.0e38) ? (T)sqrt(a) : (T)0;
+}
 // Jacobi rotation (cos, sin) that annihilates the off-diagonal g of [[a, g], [g, b]]; `rel` receives
 // |g| / sqrt(a b).  f32 uses the single-instruction reciprocal / rsqrt (~1 ulp; the Jacobi kernels are
 // VALU-issue bound and the IEEE sqrt/div sequences were ~1/4 of their instruction stream); f64 stays IEEE.
@@ -1101,7 +1108,7 @@ __global__ __launch_bounds__(1024) void jacobi_svd_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int msk = 1; msk < G; msk <<= 1) a += __shfl_xor(a, msk, G);
-    if (gl == 0) sigma[j] = sqrt(a);
+    if (gl == 0) sigma[j] = jacobi_safe_sigma(a);  // NaN-safe: the ranking below must stay a permutation
   }
   __syncthreads();
   for (int j = tid; j < l; j += 1024) {
@@ -1276,7 +1283,7 @@ __global__ __launch_bounds__(1024) void jacobi_svd_split_kernel(const T* __restr
     }
 #pragma unroll
     for (int msk = 1; msk < 16; msk <<= 1) a += __shfl_xor(a, msk, 16);
-    if (gl == 0) sigma[j] = sqrt(a);
+    if (gl == 0) sigma[j] = jacobi_safe_sigma(a);  // NaN-safe: the ranking below must stay a permutation
   }
   __syncthreads();
   for (int j = tid; j < l; j += 1024) {
@@ -1538,8 +1545,8 @@ __global__ __launch_bounds__(kRingMaxThreads) void jacobi_ring_kernel(const T* _
     va = ring_sum8(va);
     vb = ring_sum8(vb);
     if (act && g == 0) {
-      sigma[2 * proc] = va > (T)0 ? sqrt(a) : (T)-1;
-      sigma[2 * proc + 1] = vb > (T)0 ? sqrt(b) : (T)-1;
+      sigma[2 * proc] = va > (T)0 ? jacobi_safe_sigma(a) : (T)-1;
+      sigma[2 * proc + 1] = vb > (T)0 ? jacobi_safe_sigma(b) : (T)-1;
     }
   }
   __syncthreads();
@@ -1764,8 +1771,8 @@ __global__ __launch_bounds__(kRingProcPad * G) void jacobi_ring_w_kernel(const T
     const int idp = (nsw & 1) ? n2 - 1 - 2 * proc : 2 * proc;
     const int idq = (nsw & 1) ? n2 - 2 - 2 * proc : 2 * proc + 1;
     if (act && g == 0) {
-      sigma[2 * proc] = idp < l ? sqrt(a) : (T)-1;
-      sigma[2 * proc + 1] = idq < l ? sqrt(b) : (T)-1;
+      sigma[2 * proc] = idp < l ? jacobi_safe_sigma(a) : (T)-1;
+      sigma[2 * proc + 1] = idq < l ? jacobi_safe_sigma(b) : (T)-1;
     }
   }
   __syncthreads();
@@ -2158,7 +2165,7 @@ __global__ __launch_bounds__(1024) void jacobi_finish_kernel(const T* w, int64_t
     }
 #pragma unroll
     for (int msk = 1; msk < 16; msk <<= 1) a += __shfl_xor(a, msk, 16);
-    if (gl == 0) sigma[j] = sqrt(a);
+    if (gl == 0) sigma[j] = jacobi_safe_sigma(a);  // NaN-safe: the ranking below must stay a permutation
   }
   __syncthreads();
   for (int j = tid; j < l; j += 1024) {

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
   constexpr int PITCH = jmc_pitch(NC, (int)sizeof(T), LANES);
   // converged in an earlier sweep (the flags were written by earlier launches): nothing to do
   if (sweep > 0 && !(ctl->rot[sweep - 1] && ctl->big[sweep - 1])) return;
+  if (ctl->bad) return;  // non-finite input: the finish kernel reports it
   if (threadIdx.x == 0 && blockIdx.x == 0 && ctl->t_last != 0) {  // diagnostic: span of the PREVIOUS launch
     ctl->t_span += ctl->t_last - ctl->t_first;
     ctl->t_first = ~0ull;
@@ -450,7 +451,9 @@ __global__ __launch_bounds__(1024) void jmc_finish_kernel(const T* w, const T* v
     }
 #pragma unroll
     for (int msk = 1; msk < 16; msk <<= 1) a += __shfl_xor(a, msk, 16);
-    if (gl == 0) sigma[j] = sqrt(a);
+    // a non-finite column (non-finite input: ctl->bad) must not reach the ranking below -- comparisons with NaN are all
+    // false, the ranks would collide and `order` would keep uninitialised LDS, i.e. wild column indices
+    if (gl == 0) sigma[j] = jacobi_safe_sigma(a);
   }
   __syncthreads();
   for (int j = tid; j < l; j += 1024) {

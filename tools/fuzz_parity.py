@@ -11,15 +11,16 @@ from oracle import rsvd_oracle as orc  # noqa: E402
 
 
 
-def run(n_cases=200, seed=0, ctx=None, verbose=True):
+def run(n_cases=200, seed=0, ctx=None, verbose=True, wide=False):
   """Returns (violations, worst f64 deviations)."""
   rng = np.random.default_rng(seed)
   ctx = ctx or cr.Context(0)
   worst = {"ds": 0.0, "relerr": 0.0, "orth": 0.0}
   bad = 0
   for case in range(n_cases):
-      m = int(rng.integers(1, 700))
-      n = int(rng.integers(1, 400))
+      # wide: sketches of up to 352 columns (two column blocks, 2 x 2 blocked factorisations)
+      m = int(rng.integers(1, 1500 if wide else 700))
+      n = int(rng.integers(1, 700 if wide else 400))
       dtype = np.float64 if rng.random() < 0.5 else np.float32
       kind = rng.choice(["flat", "decay", "rankdef", "scaled"])
       a = rng.standard_normal((m, n))
@@ -35,7 +36,7 @@ def run(n_cases=200, seed=0, ctx=None, verbose=True):
           a = np.asfortranarray(a)
       nt = min(m, n)
       k = int(rng.integers(1, nt + 1))
-      k = min(k, 160)
+      k = min(k, 340 if wide else 160)
       p = int(rng.integers(0, 12))
       q = int(rng.integers(0, 7))
       l = min(k + p, nt)
@@ -80,6 +81,6 @@ def run(n_cases=200, seed=0, ctx=None, verbose=True):
 
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    bad, worst = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad, worst = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0, wide=len(sys.argv) > 3 and sys.argv[3] == "wide")
     print("cases", n_cases, "violations", bad, "worst f64:", {k_: "%.2e" % v for k_, v in worst.items()})
     sys.exit(1 if bad else 0)

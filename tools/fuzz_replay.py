@@ -10,10 +10,11 @@ import corrla_rs_amd as cr  # noqa: E402
 from oracle import rsvd_oracle as orc  # noqa: E402
 
 seed, want = int(sys.argv[1]), int(sys.argv[2])
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 rng = np.random.default_rng(seed)
 ctx = cr.Context(0)
 for case in range(want + 1):
-    m = int(rng.integers(1, 700)); n = int(rng.integers(1, 400))
+    m = int(rng.integers(1, 1500 if wide else 700)); n = int(rng.integers(1, 700 if wide else 400))
     dtype = np.float64 if rng.random() < 0.5 else np.float32
     kind = rng.choice(["flat", "decay", "rankdef", "scaled"])
     a = rng.standard_normal((m, n))
@@ -28,7 +29,7 @@ for case in range(want + 1):
     if rng.random() < 0.3:
         a = np.asfortranarray(a)
     nt = min(m, n)
-    k = min(int(rng.integers(1, nt + 1)), 160)
+    k = min(int(rng.integers(1, nt + 1)), 340 if wide else 160)
     p = int(rng.integers(0, 12)); q = int(rng.integers(0, 7))
     l = min(k + p, nt)
     om = rng.standard_normal((nt, l)).astype(dtype)
