@@ -310,12 +310,11 @@ struct RsvdDriver {
     // pass AND keeps them more accurate (16384 x 16384 f32, sigma_i = 0.7^i: the 10th singular value to 1.6e-5 with
     // 16 eps, to 2.3e-4 with 1100 eps); a pivot that fails all the same only costs that column (null -> re-seeded).
     // It must also stay above the rounding error of the factorisation itself, or pivots of nearly dependent columns
-    // come out negative and the column -- a direction f64 may still resolve -- is discarded as null: ~sqrt(l) eps inside
-    // the elimination kernel, ~l eps in the Schur complement of the 2 x 2 blocked form (formed by a product;
-    // tools/fuzz_parity.py seed 22 case 133 lost 2e-4 in a trailing singular value at l = 160 with 16 eps).  (Clamping
+    // come out negative and the column -- a direction f64 may still resolve -- is discarded as null: the elimination kernel
+    // stays within the 16 eps in practice (thousands of fuzz cases), the Schur complement of the 2 x 2 blocked form is formed
+    // by a product and carries ~l eps (tools/fuzz_parity.py seed 22 case 133 lost 2e-4 in a trailing singular value at l = 160 with 16 eps).  (Clamping
     // failed pivots to the shift instead keeps the span too, but the inverse factor of dozens of clamped columns overflows.)
-    double shift_rel = eps0 * std::max({16.0, 0.25 * std::sqrt((double)std::max<int64_t>(y.rows, 1)),
-                                        single ? 0.25 * (double)l : 2.0 * (double)l});
+    double shift_rel = eps0 * std::max({16.0, 0.25 * std::sqrt((double)std::max<int64_t>(y.rows, 1)), single ? 0.0 : 2.0 * (double)l});
     if (const char* e = std::getenv("CORRLA_QR_SHIFT_SCALE")) shift_rel *= std::atof(e);  // experiments
     // in-loop: a direction whose residual is below the shift would leave the pass less than half normalised; such
     // half-lifted columns measurably hurt (DMDc snapshots: 7e-7 instead of 1e-14 in the 8th singular vector), so they
