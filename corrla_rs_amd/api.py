@@ -199,7 +199,7 @@ class Context:
         del keep
         return u, s, vt
 
-    def rsvd_sharded(self, a_local, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, fused=False, shard="rows"):
+    def rsvd_sharded(self, a_local, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, fused=False, shard="rows", qr=None):
         """Sharded random_svd, one process per GPU.  shard="rows": `a_local` holds this rank's
         rows of a TALL matrix (torch CUDA tensor); returns (U_local, S, Vt) with S, Vt replicated.  shard="cols":
         `a_local` holds this rank's COLUMNS of a FAT matrix; returns (U, S, Vt_local) with U, S replicated
@@ -207,7 +207,7 @@ class Context:
         if shard not in ("rows", "cols"):
             raise ValueError("shard must be 'rows' or 'cols'")
         return self._rsvd_torch(a_local, int(n_rank), int(n_iters), int(n_oversamples), seed, omega, sharded=True, fused=fused,
-                                shard_cols=(shard == "cols"))
+                                shard_cols=(shard == "cols"), qr=qr)
 
     # ---- PCA caller (pca_rsvd.rs:56-82) ---------------------------------------------------
     def pca_sharded(self, x_local, rank, n_iter=None, n_oversamples=None, *, seed=None, omega=None, center=None):

@@ -216,12 +216,90 @@ struct RsvdDriver {
     return m_global_;
   }
 
+  // ---- Householder thin-Q (random_svd.rs:38,57 as written; CORRLA_QR_HOUSEHOLDER) ------------------------------------
+  // Row-sharded calls: every rank must take the same branch, and a shard with fewer rows than columns cannot carry its
+  // own l x l R factor -> one scalar all-reduce per call counts such shards; any -> the call keeps the default path.
+  int hh_short_shards_ = -1;
+  bool householder_usable(const Skinny<T>& y, bool sharded) {
+    if (!qr_householder) return false;
+    if (!sharded) return y.rows >= y.cols;
+    if (hh_short_shards_ < 0) hh_short_shards_ = (int)dev.allreduce_sum_host(m_local_ < y.cols ? 1 : 0);
+    return hh_short_shards_ == 0;
+  }
+  // One column panel (at most 138 columns in f32 / 97 in f64: 2 l x l must fit in LDS): TSQR over this rank's rows.
+  // Row-sharded: the P root R factors are stacked (one all-reduce of a zero-padded P l x l buffer = an all-gather), every
+  // rank takes the thin-Q of the stack redundantly (same arithmetic -> same bits) and feeds its own l x l block of it
+  // into the down sweep:  Y = diag(Q_r) [R_r] = diag(Q_r) Q' R  =>  Q = [Q_r C_r].  (R-factor exchange.)
+  void householder_panel(Skinny<T>& y, Skinny<T>& tmp, bool sharded) {
+    const int64_t l = y.cols;
+    auto h = dev.householder_up(y, tmp);
+    if (!sharded) {
+      dev.householder_down(h, y, tmp);
+      return;
+    }
+    const int64_t np = dev.nranks(), rk = dev.rank();
+    Skinny<T> stack = dev.template alloc_skinny<T>(np * l, l), t2 = dev.template alloc_skinny<T>(np * l, l);
+    Skinny<T> rv, cv;
+    rv.p = h.r_root();
+    rv.rows = rv.cols = rv.ld = rv.cols_alloc = l;
+    dev.copy_block(rv, 0, 0, l, l, stack, rk * l, 0);
+    dev.allreduce(stack.p, (size_t)stack.ld * (size_t)stack.cols_alloc);
+    dev.householder_thin_q(stack, t2);
+    cv.p = (T*)dev.alloc_zeroed_bytes((size_t)l * (size_t)l * sizeof(T));
+    cv.rows = cv.cols = cv.ld = cv.cols_alloc = l;
+    dev.copy_block(stack, rk * l, 0, l, l, cv, 0, 0);
+    dev.householder_down(h, y, tmp, (const T*)cv.p);
+  }
+  // Any width: column blocks of at most one LDS panel, block j = thin-Q of (I - Q_<j Q_<j^T) Y_j, repeated (block
+  // classical Gram-Schmidt with re-orthogonalisation around the Householder panels).  The panel Q is orthonormal
+  // whatever the rank of its input; what a repeat restores is orthogonality ACROSS blocks: a panel whose input had an
+  // overlap t = Q_<j^T X with sigma_max(t) <= 1/2 leaves (I - P) X with singular values >= 0.87, so its thin-Q is
+  // orthogonal to Q_<j to O(eps).  Full-rank sketches stop after the second pass (the first panel's output already is
+  // nearly orthogonal); a block that the first projection cancelled down to rounding noise -- noise that lies mostly IN
+  // span(Q_<j) -- takes a third.  The overlap is read on the host (this mode runs with the host in the loop anyway) from
+  // the all-reduced t, so row-sharded ranks decide alike.  The projections are tall MFMA products.
+  void householder_thin_q_any_width(Skinny<T>& y, Skinny<T>& tmp, bool sharded) {
+    const int64_t l = y.cols, m = y.rows;
+    int64_t wmax = dev.template householder_max_width<T>();
+    if (const char* e = std::getenv("CORRLA_HH_BLOCK")) wmax = std::max<int64_t>(1, std::min<int64_t>(wmax, std::atoll(e)));
+    if (l <= wmax) {
+      householder_panel(y, tmp, sharded);
+      return;
+    }
+    const int64_t nb = (l + wmax - 1) / wmax, w = (l + nb - 1) / nb;
+    std::vector<double> th;
+    for (int64_t c0 = 0; c0 < l; c0 += w) {
+      const int64_t wb = std::min(w, l - c0);
+      Skinny<T> yb = dev.template alloc_skinny<T>(m, wb), tb = dev.template alloc_skinny<T>(m, wb);
+      Skinny<T> pb = dev.template alloc_skinny<T>(m, wb);
+      dev.copy_block(y, 0, c0, m, wb, yb, 0, 0);
+      for (int pass = 0; pass < 5; ++pass) {
+        double overlap2 = 0.0;
+        if (c0 > 0) {
+          Skinny<T> t = dev.template alloc_skinny<T>(c0, wb);
+          dev.gemm_nn(as_rowmajor_transposed(y, c0), yb, t, kNone);  // Q_<j^T Y_j
+          if (sharded) dev.allreduce(t.p, (size_t)t.ld * (size_t)t.cols_alloc);
+          if (pass >= 1) {
+            th.resize((size_t)(c0 * wb));
+            dev.download_skinny(t, c0, wb, th.data());
+            for (double v : th) overlap2 += v * v;
+          }
+          dev.gemm_tn(as_rowmajor_transposed(y, c0), t, pb, kNone);  // Q_<j (Q_<j^T Y_j)
+          dev.sub_inplace(yb, pb);
+        }
+        householder_panel(yb, tb, sharded);
+        if (c0 == 0 || (pass >= 1 && overlap2 <= 0.25)) break;
+      }
+      dev.copy_block(yb, 0, 0, m, wb, y, 0, c0);
+    }
+  }
+
   int64_t orthonormalize(Skinny<T>& y, Skinny<T>& tmp, bool sharded, bool rough = false) {
     const int64_t l = y.cols;
-    if (qr_householder && !sharded && y.rows >= l && dev.template householder_fits<T>(l)) {
+    if (householder_usable(y, sharded)) {
       // random_svd.rs:38,57 as written: Householder QR, explicit thin Q (orthonormal for any rank of y)
       PhaseTimer qt0;
-      dev.householder_thin_q(y, tmp);
+      householder_thin_q_any_width(y, tmp, sharded);
       ++tm.qr_passes;
       subphase(tm.qr_gram_ms, qt0);
       return l;
@@ -609,7 +687,7 @@ struct RsvdDriver {
   // ---- power_iter, random_svd.rs:15-59 -------------------------------------------------
   // Leaves the orthonormal basis in `y` (mt x l) and returns its numerical rank.
   int64_t power_iter(const TallA<T>& a, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& y, Skinny<T>& y2) {
-    qr_householder = o.qr_householder && !o.sharded;  // no cross-rank TSQR: sharded calls keep the default path
+    qr_householder = o.qr_householder;
     m_local_ = a.mt;
     PhaseTimer pt;
     Skinny<T> om = dev.template alloc_skinny<T>(a.nt, l);
@@ -683,12 +761,13 @@ struct RsvdDriver {
   // it runs again and overwrites them.
   void random_svd_tall(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
                        T* s_dev, Skinny<T>& v_tall, const std::function<void()>& emit = {}) {
-    qr_householder = o.qr_householder && !o.sharded;  // no cross-rank TSQR: sharded calls keep the default path
+    qr_householder = o.qr_householder;
     m_local_ = a.mt;
     m_global_ = -1;
+    hh_short_shards_ = -1;
     // Householder mode has no status records to defer: the body runs with the host in the loop, which also lets it
     // complete the null vectors of an exactly singular core (see random_svd_tall_body)
-    const bool hh = qr_householder && !o.sharded && dev.template householder_fits<T>(l);
+    const bool hh = qr_householder;
     if (!hh && (dev.template device_chol_fits<T>(l) || dev.template device_chol_blocked_fits<T>(l))) {
       // Optimistic run: every Cholesky-QR status record is checked once, after the last kernel is enqueued
       // (no host synchronisation inside the call).  A record that is not clean (rank deficiency, zero or
@@ -813,7 +892,7 @@ struct RsvdDriver {
                             T* s_dev, Skinny<T>& v_tall) {
     PhaseTimer total;
     // both are written by a product before anything reads them (q: the sketch; q2: the first Y * R^-1)
-    const bool hh_tmp = qr_householder && !o.sharded;  // the Householder path stores reflectors in q2: keep it zero-filled
+    const bool hh_tmp = qr_householder;  // the Householder path stores reflectors in q2: keep it zero-filled
     Skinny<T> q = dev.template alloc_skinny_out<T>(a.mt, l);
     Skinny<T> q2 = hh_tmp ? dev.template alloc_skinny<T>(a.mt, l) : dev.template alloc_skinny_out<T>(a.mt, l);
     power_iter(a, l, n_iter, o, q, q2);  // :76-77

@@ -648,9 +648,19 @@ class HipDev {
     return l >= 1 && l <= 4096 && k::hh_lds_bytes((int)(2 * l), (int)l, sizeof(T)) <= (size_t)160 * 1024 &&
            2 * l <= 64 * k::kHhMaxRowsPerLane;
   }
-  // y (m x l, m >= l) <- thin Q of its Householder QR; tmp (same shape) receives the leaf reflectors
+  // Up sweep of the TSQR of y (m x l, m >= l): leaf reflectors -> tmp (same shape as y), tree reflectors and the root's
+  // R factor (l x l, column-major, ld = l) stay in call-lifetime device buffers named by the returned state.
   template <class T>
-  void householder_thin_q(Skinny<T>& y, Skinny<T>& tmp) {
+  struct HhState {
+    int64_t m = 0;
+    int l = 0, nleaf = 0, levels = 0, max_rows = 0;
+    std::vector<int> n_at;
+    std::vector<T*> rbuf, cbuf, taub, vbuf;
+    T* r_root() const { return rbuf[levels]; }
+  };
+  template <class T>
+  HhState<T> householder_up(Skinny<T>& y, Skinny<T>& tmp) {
+    HhState<T> h;
     const int64_t m = y.rows;
     const int l = (int)y.cols;
     if (m < l) throw Error(ST_EINVAL, "householder_thin_q: fewer rows than columns");
@@ -658,35 +668,65 @@ class HipDev {
     const int64_t br = 2 * (int64_t)l;
     const int64_t nleaf64 = m <= br ? 1 : (m + br - 1) / br;
     if (nleaf64 > 0x3fffffff) throw Error(ST_EINVAL, "householder_thin_q: too many panels");
-    const int nleaf = (int)nleaf64;
-    const int max_rows = (int)std::min<int64_t>(m, br);
-    const size_t lds = k::hh_lds_bytes(max_rows, l, sizeof(T));
-    std::vector<int> n_at{nleaf};
-    while (n_at.back() > 1) n_at.push_back((n_at.back() + 1) / 2);
-    const int levels = (int)n_at.size() - 1;
+    h.m = m;
+    h.l = l;
+    h.nleaf = (int)nleaf64;
+    h.max_rows = (int)std::min<int64_t>(m, br);
+    const size_t lds = k::hh_lds_bytes(h.max_rows, l, sizeof(T));
+    h.n_at = {h.nleaf};
+    while (h.n_at.back() > 1) h.n_at.push_back((h.n_at.back() + 1) / 2);
+    h.levels = (int)h.n_at.size() - 1;
     const size_t ll = (size_t)l * l;
-    std::vector<T*> rbuf(levels + 1), cbuf(levels + 1), taub(levels + 1), vbuf(levels + 1, nullptr);
-    for (int k_ = 0; k_ <= levels; ++k_) {
-      rbuf[k_] = (T*)alloc_bytes(ll * n_at[k_] * sizeof(T));
-      cbuf[k_] = (T*)alloc_bytes(ll * n_at[k_] * sizeof(T));
-      taub[k_] = (T*)alloc_bytes((size_t)l * n_at[k_] * sizeof(T));
-      if (k_ >= 1) vbuf[k_] = (T*)alloc_bytes(2 * ll * n_at[k_] * sizeof(T));
+    h.rbuf.resize(h.levels + 1);
+    h.cbuf.resize(h.levels + 1);
+    h.taub.resize(h.levels + 1);
+    h.vbuf.assign(h.levels + 1, nullptr);
+    for (int k_ = 0; k_ <= h.levels; ++k_) {
+      h.rbuf[k_] = (T*)alloc_bytes(ll * h.n_at[k_] * sizeof(T));
+      h.cbuf[k_] = (T*)alloc_bytes(ll * h.n_at[k_] * sizeof(T));
+      h.taub[k_] = (T*)alloc_bytes((size_t)l * h.n_at[k_] * sizeof(T));
+      if (k_ >= 1) h.vbuf[k_] = (T*)alloc_bytes(2 * ll * h.n_at[k_] * sizeof(T));
     }
-    hipLaunchKernelGGL((k::hh_leaf_factor_kernel<T>), dim3((unsigned)nleaf), dim3(k::kHhThreads), lds, stream, (const T*)y.p, y.ld,
-                       m, l, nleaf, tmp.p, tmp.ld, taub[0], rbuf[0]);
+    hipLaunchKernelGGL((k::hh_leaf_factor_kernel<T>), dim3((unsigned)h.nleaf), dim3(k::kHhThreads), lds, stream, (const T*)y.p,
+                       y.ld, m, l, h.nleaf, tmp.p, tmp.ld, h.taub[0], h.rbuf[0]);
     const size_t lds_tree = k::hh_lds_bytes(2 * l, l, sizeof(T));
-    for (int k_ = 1; k_ <= levels; ++k_)
-      hipLaunchKernelGGL((k::hh_tree_factor_kernel<T>), dim3((unsigned)n_at[k_]), dim3(k::kHhThreads), lds_tree, stream,
-                         (const T*)rbuf[k_ - 1], n_at[k_ - 1], l, vbuf[k_], taub[k_], rbuf[k_]);
-    for (int k_ = levels; k_ >= 1; --k_)
-      hipLaunchKernelGGL((k::hh_tree_apply_kernel<T>), dim3((unsigned)n_at[k_]), dim3(k::kHhThreads), lds_tree, stream,
-                         (const T*)(k_ == levels ? nullptr : cbuf[k_]), (const T*)vbuf[k_], (const T*)taub[k_], n_at[k_ - 1], l,
-                         cbuf[k_ - 1]);
-    hipLaunchKernelGGL((k::hh_leaf_apply_kernel<T>), dim3((unsigned)nleaf), dim3(k::kHhThreads), lds, stream,
-                       (const T*)(levels == 0 ? nullptr : cbuf[0]), (const T*)tmp.p, tmp.ld, (const T*)taub[0], m, l, nleaf, y.p,
-                       y.ld);
+    for (int k_ = 1; k_ <= h.levels; ++k_)
+      hipLaunchKernelGGL((k::hh_tree_factor_kernel<T>), dim3((unsigned)h.n_at[k_]), dim3(k::kHhThreads), lds_tree, stream,
+                         (const T*)h.rbuf[k_ - 1], h.n_at[k_ - 1], l, h.vbuf[k_], h.taub[k_], h.rbuf[k_]);
+    CORRLA_HIP(hipGetLastError());
+    return h;
+  }
+  // Down sweep: y <- Q [C; 0] with Q the orthogonal factor of the up sweep and C = root_coef (l x l, column-major,
+  // ld = l; nullptr = the identity, i.e. y <- the explicit thin Q).  A cross-rank TSQR passes its block of the top-level
+  // Q here (driver.hpp householder_panel).
+  template <class T>
+  void householder_down(HhState<T>& h, Skinny<T>& y, Skinny<T>& tmp, const T* root_coef = nullptr) {
+    const int l = h.l;
+    const size_t lds = k::hh_lds_bytes(h.max_rows, l, sizeof(T));
+    const size_t lds_tree = k::hh_lds_bytes(2 * l, l, sizeof(T));
+    for (int k_ = h.levels; k_ >= 1; --k_)
+      hipLaunchKernelGGL((k::hh_tree_apply_kernel<T>), dim3((unsigned)h.n_at[k_]), dim3(k::kHhThreads), lds_tree, stream,
+                         (const T*)(k_ == h.levels ? root_coef : h.cbuf[k_]), (const T*)h.vbuf[k_], (const T*)h.taub[k_],
+                         h.n_at[k_ - 1], l, h.cbuf[k_ - 1]);
+    hipLaunchKernelGGL((k::hh_leaf_apply_kernel<T>), dim3((unsigned)h.nleaf), dim3(k::kHhThreads), lds, stream,
+                       (const T*)(h.levels == 0 ? root_coef : h.cbuf[0]), (const T*)tmp.p, tmp.ld, (const T*)h.taub[0], h.m, l,
+                       h.nleaf, y.p, y.ld);
     CORRLA_HIP(hipGetLastError());
   }
+  // y (m x l, m >= l) <- thin Q of its Householder QR; tmp (same shape) receives the leaf reflectors
+  template <class T>
+  void householder_thin_q(Skinny<T>& y, Skinny<T>& tmp) {
+    HhState<T> h = householder_up(y, tmp);
+    householder_down(h, y, tmp);
+  }
+  // widest panel one workgroup can hold: 138 (f32) / 97 (f64)
+  template <class T>
+  int householder_max_width() const {
+    int w = 1;
+    while (householder_fits<T>(w + 1)) ++w;
+    return w;
+  }
+  int rank() const { return comm_rank; }
 
   template <class T>
   void set_jmc_attrs() {

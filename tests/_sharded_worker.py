@@ -30,6 +30,7 @@ def main():
 
     cb = ALLREDUCE_FN(allreduce)
     emu().corrla_emu_set_comm(cb, world)
+    emu().corrla_emu_set_rank(rank)
 
     d = np.load(os.path.join(out_dir, "input.npz"))
     a, omega = d["A"], d["omega"]
@@ -51,6 +52,7 @@ def main():
         dist.destroy_process_group()
         return
     shard_cols = "shard_cols" in d.files and int(d["shard_cols"]) == 1
+    qr = "householder" if "householder" in d.files and int(d["householder"]) == 1 else None
     for dtype in (np.float64, np.float32):
         if shard_cols:     # fat matrix, this rank's COLUMNS (lo/hi index the columns)
             n = a.shape[1]
@@ -58,7 +60,7 @@ def main():
             a_loc = np.ascontiguousarray(a[:, lo:hi].astype(dtype))
         else:
             a_loc = np.ascontiguousarray(a[lo:hi].astype(dtype))
-        u, s, vt = emu_rsvd(a_loc, k, q, p, omega=omega.astype(dtype), sharded=True, shard_cols=shard_cols)
+        u, s, vt = emu_rsvd(a_loc, k, q, p, omega=omega.astype(dtype), sharded=True, shard_cols=shard_cols, qr=qr)
         np.savez(os.path.join(out_dir, f"out_{np.dtype(dtype).name}_rank{rank}.npz"), u=u, s=s, vt=vt, lo=lo, hi=hi,
                  n_allreduce=calls["n"])
         calls["n"] = 0

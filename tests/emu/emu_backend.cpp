@@ -21,6 +21,7 @@ using namespace corrla;
 typedef void (*emu_allreduce_fn)(void* buf, uint64_t count, int is_f64);
 static emu_allreduce_fn g_allreduce = nullptr;
 static int g_nranks = 1;
+static int g_rank = 0;
 
 static inline void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
   for (int r = 0; r < 10; ++r) {
@@ -279,19 +280,38 @@ class EmuDev {
       }
     }
   }
+  // HipDev::householder_up / householder_down: the two sweeps, so that a cross-rank TSQR can put its exchange between
   template <class T>
-  void householder_thin_q(Skinny<T>& y, Skinny<T>& tmp) {
+  struct HhState {
+    int64_t m = 0;
+    int l = 0, nleaf = 0, levels = 0;
+    std::vector<int> n_at;
+    std::vector<std::vector<T>> rbuf, cbuf, taub, vbuf;
+    T* r_root() { return rbuf[levels].data(); }
+  };
+  template <class T>
+  HhState<T> householder_up(Skinny<T>& y, Skinny<T>& tmp) {
+    HhState<T> h;
     const int64_t m = y.rows;
     const int l = (int)y.cols;
     if (m < l) throw Error(ST_EINVAL, "householder_thin_q: fewer rows than columns");
     const int64_t br = 2 * (int64_t)l;
     const int nleaf = (int)(m <= br ? 1 : (m + br - 1) / br);
     auto row0 = [&](int i) { return (m * (int64_t)i) / nleaf; };
-    std::vector<int> n_at{nleaf};
+    std::vector<int>& n_at = h.n_at;
+    n_at = {nleaf};
     while (n_at.back() > 1) n_at.push_back((n_at.back() + 1) / 2);
     const int levels = (int)n_at.size() - 1;
+    h.m = m;
+    h.l = l;
+    h.nleaf = nleaf;
+    h.levels = levels;
     const size_t ll = (size_t)l * l;
-    std::vector<std::vector<T>> rbuf(levels + 1), cbuf(levels + 1), taub(levels + 1), vbuf(levels + 1);
+    auto &rbuf = h.rbuf, &cbuf = h.cbuf, &taub = h.taub, &vbuf = h.vbuf;
+    rbuf.resize(levels + 1);
+    cbuf.resize(levels + 1);
+    taub.resize(levels + 1);
+    vbuf.resize(levels + 1);
     for (int k = 0; k <= levels; ++k) {
       rbuf[k].assign(ll * n_at[k], 0);
       cbuf[k].assign(ll * n_at[k], 0);
@@ -330,8 +350,19 @@ class EmuDev {
         for (int c = 0; c < l; ++c)
           for (int r = 0; r < l; ++r) rbuf[k][(size_t)t * ll + (size_t)c * l + r] = r <= c ? P[(size_t)c * rows + r] : (T)0;
       }
-    auto coeff = [&](int k, int t, int r, int c) -> T {  // root: identity
-      return k == levels ? (r == c ? (T)1 : (T)0) : cbuf[k][(size_t)t * ll + (size_t)c * l + r];
+    return h;
+  }
+  template <class T>
+  void householder_down(HhState<T>& h, Skinny<T>& y, Skinny<T>& tmp, const T* root_coef = nullptr) {
+    const int64_t m = h.m;
+    const int l = h.l, nleaf = h.nleaf, levels = h.levels;
+    const size_t ll = (size_t)l * l;
+    auto row0 = [&](int i) { return (m * (int64_t)i) / nleaf; };
+    auto &n_at = h.n_at;
+    auto &cbuf = h.cbuf, &taub = h.taub, &vbuf = h.vbuf;
+    auto coeff = [&](int k, int t, int r, int c) -> T {  // root: identity unless a coefficient block is given
+      if (k == levels) return root_coef ? root_coef[(size_t)c * l + r] : (r == c ? (T)1 : (T)0);
+      return cbuf[k][(size_t)t * ll + (size_t)c * l + r];
     };
     for (int k = levels; k >= 1; --k)  // tree (down)
       for (int t = 0; t < n_at[k]; ++t) {
@@ -363,6 +394,18 @@ class EmuDev {
         for (int r = 0; r < rows; ++r) y.p[(int64_t)c * y.ld + r0 + r] = P[(size_t)c * rows + r];
     }
   }
+  template <class T>
+  void householder_thin_q(Skinny<T>& y, Skinny<T>& tmp) {
+    auto h = householder_up(y, tmp);
+    householder_down(h, y, tmp);
+  }
+  template <class T>
+  int householder_max_width() const {
+    int w = 1;
+    while (householder_fits<T>(w + 1)) ++w;
+    return w;
+  }
+  int rank() const { return g_rank; }
 
   template <class T>
   void copy_block(const Skinny<T>& src, int64_t r0, int64_t c0, int64_t rows, int64_t cols, Skinny<T>& dst, int64_t dr0,
@@ -717,6 +760,7 @@ EMU_API void corrla_emu_set_comm(emu_allreduce_fn fn, int nranks) {
   g_allreduce = fn;
   g_nranks = nranks;
 }
+EMU_API void corrla_emu_set_rank(int rank) { g_rank = rank; }
 #define EMU_DEFINE(SUF, T)                                                                                             \
   EMU_API int corrla_emu_rsvd_##SUF(const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank, int64_t n_iter,    \
                             int64_t p, const corrla_opts* o, T* u, int64_t ldu, T* s, T* vt, int64_t ldvt,             \

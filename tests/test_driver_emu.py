@@ -303,14 +303,38 @@ def test_householder_tsqr_is_orthonormal_for_rank_deficient_sketches():
     assert np.max(np.abs(u.T @ u - np.eye(6))) < 1e-10
 
 
-def test_householder_flag_on_the_sharded_entry_point_takes_the_default_path():
-    """Row-sharded calls have no cross-rank TSQR: the flag is accepted and the CholeskyQR2 path runs (same numbers)."""
+def test_householder_flag_on_the_sharded_entry_point():
+    """Row-sharded calls run the cross-rank TSQR (world size 1 here: the stack of root R factors is the one R, its thin-Q
+    a diagonal of signs): same factorisation as the unsharded Householder call and as the default path."""
     rng = np.random.default_rng(14)
     a = rng.standard_normal((300, 40))
     om = rng.standard_normal((40, 14))
     u1, s1, vt1 = emu_rsvd(a, 8, 2, 6, omega=om, sharded=True, qr="householder")
+    u2, s2, vt2 = emu_rsvd(a, 8, 2, 6, omega=om, qr="householder")
     u0, s0, vt0 = emu_rsvd(a, 8, 2, 6, omega=om, sharded=True)
-    assert np.array_equal(s0, s1) and np.array_equal(u0, u1) and np.array_equal(vt0, vt1)
+    for (u, s, vt) in ((u2, s2, vt2), (u0, s0, vt0)):
+        assert np.allclose(s, s1, rtol=1e-12)
+        assert np.linalg.norm((u * s.ravel()) @ vt - (u1 * s1.ravel()) @ vt1) <= 1e-11 * np.linalg.norm(a)
+    assert np.max(np.abs(u1.T @ u1 - np.eye(8))) < 1e-13
+
+
+@pytest.mark.parametrize("dtype,width", [(np.float64, 98), (np.float64, 200), (np.float32, 139), (np.float32, 300)])
+def test_householder_wider_than_one_panel_goes_through_column_blocks(dtype, width):
+    """l > 138 (f32) / 97 (f64): one 2 l x l panel no longer fits in LDS; column blocks of at most one panel, each the
+    thin-Q of (I - Q Q^T) Y_j taken twice around the Householder panels.  Orthonormal to O(eps) and spanning what the
+    oracle's QR spans, also for a sketch of rank 5."""
+    rng = np.random.default_rng(width)
+    m, n = 900, 320
+    eps = np.finfo(dtype).eps
+    a = (rng.standard_normal((m, n)) * (0.995 ** np.arange(n))).astype(dtype)
+    om = rng.standard_normal((n, width)).astype(dtype)
+    q = emu_power_iter(a, width, 4, omega=om, qr="householder").astype(np.float64)
+    assert np.max(np.abs(q.T @ q - np.eye(width))) < 200 * eps
+    qo = orc.power_iter(a.astype(np.float64), om.astype(np.float64), 4)
+    assert np.linalg.norm(qo - q @ (q.T @ qo)) <= (1e-9 if dtype == np.float64 else 2e-2) * np.sqrt(width)
+    low = (rng.standard_normal((m, 5)) @ rng.standard_normal((5, n))).astype(dtype)
+    q = emu_power_iter(low, width, 1, omega=om, qr="householder").astype(np.float64)
+    assert np.max(np.abs(q.T @ q - np.eye(width))) < 200 * eps
 
 
 @pytest.mark.parametrize("q", [0, 1, 2, 3, 5])

@@ -582,11 +582,12 @@ def test_householder_tsqr_rank_deficient_and_fallbacks(ctx, torch, monkeypatch):
     u, s, vt = ctx.rsvd(a, 10, 2, 10, seed=1, qr="householder")
     assert np.allclose(s[:4, 0], np.linalg.svd(a, compute_uv=False)[:4], rtol=1e-10) and np.all(s[4:, 0] < 1e-9 * s[0, 0])
     assert np.max(np.abs(u.T @ u - np.eye(10))) < 1e-10 and np.max(np.abs(vt @ vt.T - np.eye(10))) < 1e-10
-    # a sketch wider than one LDS panel (l = 160 f64) takes the default path; CUDA tensors and the environment switch
+    # a sketch wider than one LDS panel (l = 160 f64) goes through column blocks; CUDA tensors and the environment switch
     b = rng.standard_normal((2000, 400))
     u1, s1, vt1 = ctx.rsvd(b, 150, 1, 10, seed=2, qr="householder")
     u0, s0, vt0 = ctx.rsvd(b, 150, 1, 10, seed=2)
-    assert np.array_equal(s0, s1)
+    assert np.allclose(s0, s1, rtol=1e-11) and not np.array_equal(u0, u1)
+    assert np.linalg.norm((u0 * s0.ravel()) @ vt0 - (u1 * s1.ravel()) @ vt1) < 1e-10 * np.linalg.norm(b)
     bt = torch.as_tensor(b[:, :100].copy(), device="cuda")
     ud, sd, vtd = ctx.rsvd(bt, 20, 2, 10, seed=4, qr="householder")
     monkeypatch.setenv("CORRLA_QR", "householder")
@@ -596,6 +597,60 @@ def test_householder_tsqr_rank_deficient_and_fallbacks(ctx, torch, monkeypatch):
     assert torch.equal(sd, se) and torch.allclose(sd, sc, rtol=1e-10) and not torch.equal(ud, uc)
     with pytest.raises(ValueError):
         ctx.rsvd(b, 10, 1, 5, qr="givens")
+
+
+@pytest.mark.parametrize("m,n,width,dtype", [(6000, 400, 139, np.float32), (6000, 400, 352, np.float32), (20000, 300, 98, np.float64),
+                                             (8000, 600, 266, np.float64), (400, 360, 352, np.float64)])
+def test_householder_wider_than_one_panel_goes_through_column_blocks(ctx, m, n, width, dtype):
+    """l > 138 (f32) / 97 (f64) up to the library's 352: column blocks of at most one LDS panel, each the thin-Q of
+    (I - Q Q^T) Y_j repeated around the Householder panels until the overlap the panel saw was small.  Q orthonormal to
+    O(eps) and spanning the oracle's Householder Q; orthonormal also for a sketch of rank 5 (random_svd.rs:38,57 has no
+    width limit and no rank condition)."""
+    from oracle import rsvd_oracle as orc
+    rng = np.random.default_rng(m + width)
+    eps = np.finfo(dtype).eps
+    a = rng.standard_normal((m, n)).astype(dtype)
+    om = rng.standard_normal((n, width)).astype(dtype)
+    q64 = ctx.power_iter(a, width, 1, omega=om, qr="householder").astype(np.float64)
+    qo = orc.power_iter(a.astype(np.float64), om.astype(np.float64), 1)
+    assert np.max(np.abs(q64.T @ q64 - np.eye(width))) < 100 * eps
+    assert np.linalg.norm(q64 @ (q64.T @ qo) - qo) < (1e-10 if dtype == np.float64 else 2e-3)
+    low = (rng.standard_normal((m, 5)) @ rng.standard_normal((5, n))).astype(dtype)
+    q64 = ctx.power_iter(low, width, 1, omega=om, qr="householder").astype(np.float64)
+    assert np.max(np.abs(q64.T @ q64 - np.eye(width))) < 100 * eps
+    u, s, vt = ctx.rsvd(a, width - 10, 4, 10, omega=om, qr="householder")
+    uo, so, vo = orc.random_svd(a, width - 10, 4, 10, omega=om)
+    assert np.max(np.abs(s.ravel() - so.ravel())) < (1e-9 if dtype == np.float64 else 2e-4) * so[0, 0]
+    assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vo)) < (1e-9 if dtype == np.float64 else 1e-5)
+
+
+def test_householder_on_the_sharded_entry_point_world_size_1_rccl(torch, monkeypatch):
+    """Cross-rank TSQR on a real one-rank RCCL communicator with every all-reduce issued (the stack of root R factors
+    is the one R; the N = 2 exchange runs on the CPU through the same driver, tests/test_sharded_gloo.py): one panel
+    (l = 26), column blocks (l = 200 f32) and a rank-deficient input; same factorisation as the unsharded Householder
+    call and as the default path."""
+    import corrla_rs_amd as cr
+    c = cr.Context(0)
+    c.comm_init(cr.Context.unique_id(), 0, 1)
+    monkeypatch.setenv("CORRLA_FORCE_ALLREDUCE", "1")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for (m, n, k, dt, tol) in ((3000, 200, 16, torch.float32, 2e-5), (5000, 400, 190, torch.float32, 5e-5), (3000, 200, 16, torch.float64, 1e-11)):
+        a = torch.randn((m, n), dtype=dt, device="cuda", generator=g)
+        om = np.random.default_rng(2).standard_normal((n, k + 10)).astype(np.float32 if dt == torch.float32 else np.float64)
+        u1, s1, vt1 = c.rsvd_sharded(a, k, 4, 10, omega=om, qr="householder")
+        u2, s2, vt2 = c.rsvd(a, k, 4, 10, omega=om, qr="householder")
+        u0, s0, vt0 = c.rsvd(a, k, 4, 10, omega=om)
+        eye = torch.eye(k, dtype=torch.float64, device="cuda")
+        assert (u1.double().T @ u1.double() - eye).abs().max().item() < 10 * tol
+        for (u, s, vt) in ((u2, s2, vt2), (u0, s0, vt0)):
+            assert (s - s1).abs().max().item() <= tol * s1[0].item() * 10
+            assert torch.linalg.norm((u * s.ravel()) @ vt - (u1 * s1.ravel()) @ vt1).item() <= 100 * tol * torch.linalg.norm(a).item()
+    low = torch.randn((3000, 4), dtype=torch.float64, device="cuda", generator=g) @ torch.randn((4, 60), dtype=torch.float64, device="cuda", generator=g)
+    u, s, vt = c.rsvd_sharded(low, 10, 2, 10, seed=3, qr="householder")
+    assert (u.T @ u - torch.eye(10, dtype=torch.float64, device="cuda")).abs().max().item() < 1e-10
+    assert torch.all(s.ravel()[4:] < 1e-9 * s.ravel()[0])
+    monkeypatch.delenv("CORRLA_FORCE_ALLREDUCE")
+    c.close()
 
 
 # ---- SURVEY 8 f3: DMDc / POD with the n_x- and N-sized factors resident on the device ---------------------------

@@ -141,3 +141,57 @@ def test_sample_sharded_pca_world2():
                 assert np.allclose(outs[0]["s"], s1, rtol=tol, atol=tol * s1[0, 0])
                 cg = outs[0]["comps"].astype(np.float64)
                 assert np.linalg.norm(cg.T @ cg - c1.astype(np.float64).T @ c1.astype(np.float64)) < 200 * tol
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("case", ["one_panel", "column_blocks", "rank_deficient"])
+def test_row_sharded_householder_tsqr_world2(case):
+    """CORRLA_QR_HOUSEHOLDER on the row-sharded entry point (SURVEY 8e, R-factor exchange): every rank reduces its rows
+    by TSQR, the two root R factors are stacked by one all-reduce, the thin-Q of the stack is taken redundantly and each
+    rank applies its block of it on the way down.  `column_blocks`: a sketch wider than one LDS panel (l = 110 > 97 in
+    f64) goes through column blocks with two projection + panel passes each.  `rank_deficient`: exact rank 4 < l, the
+    Householder Q is orthonormal whatever the rank (random_svd.rs:38,57), across the shards too."""
+    rng = np.random.default_rng(5)
+    if case == "one_panel":
+        m, n, k, q, p = 301, 64, 10, 4, 6
+        a = rng.standard_normal((m, n))
+        port = "29549"
+    elif case == "column_blocks":
+        m, n, k, q, p = 700, 130, 100, 4, 10
+        a = rng.standard_normal((m, n)) * (0.998 ** np.arange(n))
+        port = "29551"
+    else:
+        m, n, k, q, p = 90, 30, 8, 5, 8
+        a = rng.standard_normal((m, 4)) @ rng.standard_normal((4, n))
+        port = "29553"
+    l = min(k + p, n)
+    omega = rng.standard_normal((n, l))
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "input.npz"), A=a, omega=omega, k=k, q=q, p=p, householder=1,
+                 splits=np.array([0, m // 3, m]))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "_sharded_worker.py"), td]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        ex = np.linalg.svd(a, compute_uv=False)
+        for dtype, tol in ((np.float64, 1e-10), (np.float32, 5e-5)):
+            name = np.dtype(dtype).name
+            outs = [np.load(os.path.join(td, f"out_{name}_rank{r_}.npz")) for r_ in range(2)]
+            u = np.vstack([o["u"] for o in outs]).astype(np.float64)
+            s, vt = outs[0]["s"].astype(np.float64), outs[0]["vt"].astype(np.float64)
+            assert np.array_equal(outs[0]["s"], outs[1]["s"]) and np.array_equal(outs[0]["vt"], outs[1]["vt"])
+            assert np.max(np.abs(u.T @ u - np.eye(k))) < 100 * tol
+            assert np.max(np.abs(vt @ vt.T - np.eye(k))) < 100 * tol
+            if case == "rank_deficient":
+                assert np.allclose(s.ravel()[:4], ex[:4], rtol=100 * tol) and np.all(s.ravel()[4:] < 100 * tol * ex[0])
+                assert np.linalg.norm((u * s.ravel()) @ vt - a) <= 100 * tol * np.linalg.norm(a)
+                continue
+            # same factorisation as the single-rank Householder call and as the oracle
+            u1, s1, vt1 = emu_rsvd(a.astype(dtype), k, q, p, omega=omega.astype(dtype), qr="householder")
+            assert np.max(np.abs(s - s1)) <= tol * s1[0, 0]
+            rec = (u * s.ravel()) @ vt
+            rec1 = (u1.astype(np.float64) * s1.ravel()) @ vt1
+            assert np.linalg.norm(rec - rec1) <= 100 * tol * np.linalg.norm(rec1)
+            uo, so, vto = orc.random_svd(a.astype(dtype), k, q, p, omega=omega.astype(dtype))
+            assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-5
