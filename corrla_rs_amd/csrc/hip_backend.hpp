@@ -635,18 +635,26 @@ class HipDev {
   template <class T>
   void set_tsqr_attrs() {
     const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_leaf_factor_kernel<T>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_tree_factor_kernel<T>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_tree_apply_kernel<T>, attr, 160 * 1024));
-    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_leaf_apply_kernel<T>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_leaf_factor_kernel<T, false>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_tree_factor_kernel<T, false>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_tree_apply_kernel<T, false>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_leaf_apply_kernel<T, false>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_leaf_factor_kernel<T, true>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_tree_factor_kernel<T, true>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_tree_apply_kernel<T, true>, attr, 160 * 1024));
+    CORRLA_HIP(hipFuncSetAttribute((const void*)k::hh_leaf_apply_kernel<T, true>, attr, 160 * 1024));
   }
 
   // ---- Householder TSQR with explicit thin Q (tsqr_kernels.hpp) -------------------------------------------
-  // one 2 l x l panel must fit in LDS: l <= 138 (f32) / 97 (f64)
+  // one 2 l x l panel (plus the 16 x 16 T and Gram blocks of the blocked form) must fit in LDS: l <= 142 (f32) / 99 (f64)
+  bool hh_wy_ = env_int("CORRLA_HH_WY", 1) != 0;  // blocked compact-WY panels on the MFMA units (0: the unblocked panels)
+  template <class T>
+  size_t hh_panel_lds(int rows, int l) const {
+    return hh_wy_ ? k::hh_wy_lds_bytes(rows, l, sizeof(T)) : k::hh_lds_bytes(rows, l, sizeof(T));
+  }
   template <class T>
   bool householder_fits(int64_t l) const {
-    return l >= 1 && l <= 4096 && k::hh_lds_bytes((int)(2 * l), (int)l, sizeof(T)) <= (size_t)160 * 1024 &&
-           2 * l <= 64 * k::kHhMaxRowsPerLane;
+    return l >= 1 && l <= 4096 && hh_panel_lds<T>((int)(2 * l), (int)l) <= (size_t)160 * 1024 && 2 * l <= 64 * k::kHhMaxRowsPerLane;
   }
   // Up sweep of the TSQR of y (m x l, m >= l): leaf reflectors -> tmp (same shape as y), tree reflectors and the root's
   // R factor (l x l, column-major, ld = l) stay in call-lifetime device buffers named by the returned state.
@@ -655,7 +663,7 @@ class HipDev {
     int64_t m = 0;
     int l = 0, nleaf = 0, levels = 0, max_rows = 0;
     std::vector<int> n_at;
-    std::vector<T*> rbuf, cbuf, taub, vbuf;
+    std::vector<T*> rbuf, cbuf, taub, vbuf, tbuf;  // tbuf: the T factors of the 16-column blocks (blocked form)
     T* r_root() const { return rbuf[levels]; }
   };
   template <class T>
@@ -672,7 +680,7 @@ class HipDev {
     h.l = l;
     h.nleaf = (int)nleaf64;
     h.max_rows = (int)std::min<int64_t>(m, br);
-    const size_t lds = k::hh_lds_bytes(h.max_rows, l, sizeof(T));
+    const size_t lds = hh_panel_lds<T>(h.max_rows, l);
     h.n_at = {h.nleaf};
     while (h.n_at.back() > 1) h.n_at.push_back((h.n_at.back() + 1) / 2);
     h.levels = (int)h.n_at.size() - 1;
@@ -681,18 +689,23 @@ class HipDev {
     h.cbuf.resize(h.levels + 1);
     h.taub.resize(h.levels + 1);
     h.vbuf.assign(h.levels + 1, nullptr);
+    h.tbuf.assign(h.levels + 1, nullptr);
+    const size_t tsz = (size_t)k::hh_wy_panels(l) * k::kWyNb * k::kWyNb;
     for (int k_ = 0; k_ <= h.levels; ++k_) {
+      if (hh_wy_) h.tbuf[k_] = (T*)alloc_bytes(tsz * h.n_at[k_] * sizeof(T));
       h.rbuf[k_] = (T*)alloc_bytes(ll * h.n_at[k_] * sizeof(T));
       h.cbuf[k_] = (T*)alloc_bytes(ll * h.n_at[k_] * sizeof(T));
       h.taub[k_] = (T*)alloc_bytes((size_t)l * h.n_at[k_] * sizeof(T));
       if (k_ >= 1) h.vbuf[k_] = (T*)alloc_bytes(2 * ll * h.n_at[k_] * sizeof(T));
     }
-    hipLaunchKernelGGL((k::hh_leaf_factor_kernel<T>), dim3((unsigned)h.nleaf), dim3(k::kHhThreads), lds, stream, (const T*)y.p,
-                       y.ld, m, l, h.nleaf, tmp.p, tmp.ld, h.taub[0], h.rbuf[0]);
-    const size_t lds_tree = k::hh_lds_bytes(2 * l, l, sizeof(T));
+    auto leaf = hh_wy_ ? k::hh_leaf_factor_kernel<T, true> : k::hh_leaf_factor_kernel<T, false>;
+    auto tree = hh_wy_ ? k::hh_tree_factor_kernel<T, true> : k::hh_tree_factor_kernel<T, false>;
+    hipLaunchKernelGGL(leaf, dim3((unsigned)h.nleaf), dim3(k::kHhThreads), lds, stream, (const T*)y.p, y.ld, m, l, h.nleaf, tmp.p,
+                       tmp.ld, h.taub[0], h.rbuf[0], h.tbuf[0]);
+    const size_t lds_tree = hh_panel_lds<T>(2 * l, l);
     for (int k_ = 1; k_ <= h.levels; ++k_)
-      hipLaunchKernelGGL((k::hh_tree_factor_kernel<T>), dim3((unsigned)h.n_at[k_]), dim3(k::kHhThreads), lds_tree, stream,
-                         (const T*)h.rbuf[k_ - 1], h.n_at[k_ - 1], l, h.vbuf[k_], h.taub[k_], h.rbuf[k_]);
+      hipLaunchKernelGGL(tree, dim3((unsigned)h.n_at[k_]), dim3(k::kHhThreads), lds_tree, stream, (const T*)h.rbuf[k_ - 1],
+                         h.n_at[k_ - 1], l, h.vbuf[k_], h.taub[k_], h.rbuf[k_], h.tbuf[k_]);
     CORRLA_HIP(hipGetLastError());
     return h;
   }
@@ -704,13 +717,15 @@ class HipDev {
     const int l = h.l;
     const size_t lds = k::hh_lds_bytes(h.max_rows, l, sizeof(T));
     const size_t lds_tree = k::hh_lds_bytes(2 * l, l, sizeof(T));
+    auto tree = hh_wy_ ? k::hh_tree_apply_kernel<T, true> : k::hh_tree_apply_kernel<T, false>;
+    auto leaf = hh_wy_ ? k::hh_leaf_apply_kernel<T, true> : k::hh_leaf_apply_kernel<T, false>;
     for (int k_ = h.levels; k_ >= 1; --k_)
-      hipLaunchKernelGGL((k::hh_tree_apply_kernel<T>), dim3((unsigned)h.n_at[k_]), dim3(k::kHhThreads), lds_tree, stream,
+      hipLaunchKernelGGL(tree, dim3((unsigned)h.n_at[k_]), dim3(k::kHhThreads), lds_tree, stream,
                          (const T*)(k_ == h.levels ? root_coef : h.cbuf[k_]), (const T*)h.vbuf[k_], (const T*)h.taub[k_],
-                         h.n_at[k_ - 1], l, h.cbuf[k_ - 1]);
-    hipLaunchKernelGGL((k::hh_leaf_apply_kernel<T>), dim3((unsigned)h.nleaf), dim3(k::kHhThreads), lds, stream,
+                         h.n_at[k_ - 1], l, h.cbuf[k_ - 1], (const T*)h.tbuf[k_]);
+    hipLaunchKernelGGL(leaf, dim3((unsigned)h.nleaf), dim3(k::kHhThreads), lds, stream,
                        (const T*)(h.levels == 0 ? root_coef : h.cbuf[0]), (const T*)tmp.p, tmp.ld, (const T*)h.taub[0], h.m, l,
-                       h.nleaf, y.p, y.ld);
+                       h.nleaf, y.p, y.ld, (const T*)h.tbuf[0]);
     CORRLA_HIP(hipGetLastError());
   }
   // y (m x l, m >= l) <- thin Q of its Householder QR; tmp (same shape) receives the leaf reflectors

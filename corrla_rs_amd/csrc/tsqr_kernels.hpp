@@ -20,6 +20,8 @@
 #include <cstdint>
 #include <type_traits>
 
+#include "hip_kernels.hpp"  // MT<T>: the MFMA wrappers and their register layouts
+
 namespace corrla {
 namespace k {
 
@@ -59,6 +61,11 @@ __device__ __forceinline__ T hh_wave_sum(T x) {
   return hh_readlane63(x);
 }
 
+// Barrier that orders LDS traffic only.  The panel loops store tau / T values to global memory that this kernel never
+// reads back; a __syncthreads() waits for every outstanding global store as well (vmcnt(0)), i.e. a full write round trip
+// (~2 us) per reflector step -- which was the whole cost of a step.
+__device__ __forceinline__ void hh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __host__ __device__ inline int hh_pitch(int rows) { return (rows + 3) & ~3; }
 __host__ __device__ inline size_t hh_lds_bytes(int max_rows, int l, size_t esz) {
   return (size_t)hh_pitch(max_rows) * (size_t)l * esz + 64;
@@ -96,7 +103,7 @@ __device__ void hh_factor_panel(T* P, int RP, int rows, int l, T* tau_out) {
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i) xr[i] *= scale;  // v below the diagonal
-    __syncthreads();  // everyone has read column j
+    hh_lds_barrier();  // everyone has read column j
     if (wave == 0) {
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
@@ -147,7 +154,7 @@ __device__ void hh_factor_panel(T* P, int RP, int rows, int l, T* tau_out) {
         }
       }
     }
-    __syncthreads();  // column j + 1 is complete before the next reflector is formed
+    hh_lds_barrier();  // column j + 1 is complete before the next reflector is formed
   }
 }
 
@@ -214,15 +221,355 @@ __device__ void hh_apply_panel(T* P, int RP, int rows, int l, const T* __restric
   }
 }
 
+// ---- blocked (compact WY) panels: reflector steps inside 16-column blocks, everything else on the MFMA units ------------
+// H_0 ... H_{15} of one block = I - V T V^T (V: unit lower trapezoidal, T: 16 x 16 upper triangular, LAPACK xLARFT).
+//   factor : (a) the block's columns live in the registers of one wave each; reflector jj is formed by its owner, written
+//                to LDS, and applied by the waves of the later columns of the block: ONE barrier per reflector and no
+//                work outside the block;
+//            (b) wave 0 takes G = V^T V with one MFMA chain and runs the T recurrence (lane i = row i of T);
+//            (c) trailing columns, one 16-column tile per wave:  W = V^T A (MFMA, K = rows),  TW = T^T W,  A -= V TW.
+//                W and TW never leave the registers: the D registers of one product are the B operand of the next, with
+//                the reduction index permuted to the D layout (step i of a 16-deep product takes k = drow(lane, i)).
+//   apply  : P <- (I - V T V^T) P block by block in reverse, V and T streamed from global memory (L1 / L2 resident; the
+//            panel fills the LDS); a wave owns its 16-column tiles for the whole panel: no barriers.
+// tau = 0 (a column that is already reduced) gives a zero column in T: the reflector drops out, as in the unblocked code.
+constexpr int kWyNb = 16;
+constexpr int kWyPipe = 8;      // k-steps whose operand loads are issued before their MFMAs
+constexpr int kWyRowTiles = 3;  // 16-row tiles of the rank-16 update in flight together
+static_assert(kHhWaves >= kWyNb, "one wave per column of a block");
+static_assert(kHhMaxRowsPerLane * 64 / 2 / 16 + 1 <= kHhWaves - 1, "trailing tiles of a block: one wave each, the last wave builds T");
+constexpr int kWyExtra = 2 * kWyNb * kWyNb + kWyNb;  // Ts, Rs (parked diagonal block), tau_s (elements) in front of the panel
+__host__ __device__ inline size_t hh_wy_lds_bytes(int max_rows, int l, size_t esz) {
+  return hh_lds_bytes(max_rows, l, esz) + (size_t)kWyExtra * esz;
+}
+__host__ __device__ inline int hh_wy_panels(int l) { return (l + kWyNb - 1) / kWyNb; }
+
+// entry (r, c) of the block's V as the MFMA operands need it.  V is stored CLEAN (explicit 1 on the diagonal, 0 above
+// it: the factor kernels park the R entries of the block's 16 x 16 diagonal block in LDS while the block is being applied,
+// and write clean reflectors to global memory for the down sweep), so only the range masks remain.  Columns past the
+// block's end are read clamped (finite values) and meet zero rows / columns of T.
+template <class T>
+__device__ __forceinline__ T wy_v(const T* __restrict__ V, int64_t ldv, int rows, int r, int c, int cend) {
+  const T val = V[(int64_t)min(c, cend - 1) * ldv + min(r, rows - 1)];  // unconditional (clamped) load, then select
+  return r < rows ? val : (T)0;
+}
+// which D register / lane group of an MFMA result holds row k (inverse of MT<T>::drow)
+template <class T>
+struct WyD;
+template <>
+struct WyD<float> {
+  static constexpr int reg(int k) { return k & 3; }
+  static constexpr int grp(int k) { return k >> 2; }
+};
+template <>
+struct WyD<double> {
+  static constexpr int reg(int k) { return k >> 2; }
+  static constexpr int grp(int k) { return k & 3; }
+};
+// reciprocal / square root of the reflector scalars: hardware approximation + Newton steps to (nearly) the last bit
+// instead of the IEEE division / square-root sequences, which sat on the critical path of every reflector step
+__device__ __forceinline__ float hh_rcp(float x) {
+  const float y = __builtin_amdgcn_rcpf(x);
+  return fmaf(y, fmaf(-x, y, 1.0f), y);
+}
+__device__ __forceinline__ double hh_rcp(double x) {
+  const double y = jr_rcp(x);
+  return fma(y, fma(-x, y, 1.0), y);
+}
+__device__ __forceinline__ float hh_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double hh_sqrt(double x) {
+  const double y = jr_rsq(x), s0 = x * y;
+  return fma(0.5 * y, fma(-s0, s0, x), s0);
+}
+__device__ __forceinline__ float hh_readlane(float x, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+__device__ __forceinline__ double hh_readlane(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+// sum over rows [k0, rows) of A(r) B(r)^T contributions of an MFMA product whose operands are r-contiguous columns
+// (acol / bcol: this lane's column; lane group g supplies row 4 s + g of step s).  kWyPipe steps per trip, their loads
+// issued together before their MFMAs; whole trips read through one address with immediate offsets (no clamps, no
+// masks) and only the last partial trip is masked.  (Prefetching the next trip across the MFMAs measured slower: the
+// register copies and the second accumulator cost more than the exposed LDS latency.)
+template <class T>
+__device__ __forceinline__ typename MT<T>::acc_t wy_kdot(const T* acol, const T* bcol, int k0, int rows, int g) {
+  typedef MT<T> M;
+  typedef typename M::acc_t acc_t;
+  auto load = [&](int kk, T(&av)[kWyPipe], T(&bv)[kWyPipe]) {
+    if (kk + 4 * kWyPipe <= rows) {
+      const T* qa = acol + kk + g;
+      const T* qb = bcol + kk + g;
+#pragma unroll
+      for (int u = 0; u < kWyPipe; ++u) {
+        av[u] = qa[4 * u];
+        bv[u] = qb[4 * u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kWyPipe; ++u) {
+        const int r = kk + 4 * u + g, rc = min(r, rows - 1);
+        const T xa = acol[rc], xb = bcol[rc];
+        av[u] = r < rows ? xa : (T)0;
+        bv[u] = r < rows ? xb : (T)0;
+      }
+    }
+  };
+  acc_t w0 = {0, 0, 0, 0};
+  for (int kk = k0; kk < rows; kk += 4 * kWyPipe) {
+    T a0[kWyPipe], b0[kWyPipe];
+    load(kk, a0, b0);
+#pragma unroll
+    for (int u = 0; u < kWyPipe; ++u) w0 = M::mma(a0[u], b0[u], w0);
+  }
+  return w0;
+}
+
+// This lane's tile column pc (rows [j0, rows)) -= V(:, block) TW: 16-row tiles, kWyRowTiles per trip (loads, MFMAs,
+// stores); whole trips unmasked, the last partial trip masked.
+template <class T>
+__device__ __forceinline__ void wy_update(T* pc, bool cok, const T* V, int64_t ldv, int j0, int cend, int rows,
+                                          typename MT<T>::acc_t tw, int lane) {
+  typedef MT<T> M;
+  typedef typename M::acc_t acc_t;
+  constexpr int RT = kWyRowTiles, STEP = 16 * RT;
+  const int n16 = lane & 15;
+  const T* vc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vc[i] = V + (int64_t)min(j0 + M::drow(lane, i), cend - 1) * ldv;
+  auto load = [&](int r0, acc_t(&c)[RT], T(&va)[RT][4]) {
+    if (r0 + STEP <= rows) {
+#pragma unroll
+      for (int u = 0; u < RT; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          c[u][i] = pc[r0 + 16 * u + M::drow(lane, i)];
+          va[u][i] = -vc[i][r0 + 16 * u + n16];
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < RT; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = r0 + 16 * u + M::drow(lane, i), rv = r0 + 16 * u + n16;
+          const T xc = pc[min(r, rows - 1)], xv = vc[i][min(rv, rows - 1)];
+          c[u][i] = r < rows ? xc : (T)0;
+          va[u][i] = rv < rows ? -xv : (T)0;
+        }
+    }
+  };
+  for (int r0 = j0; r0 < rows; r0 += STEP) {
+    acc_t c0[RT];
+    T v0[RT][4];
+    load(r0, c0, v0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int u = 0; u < RT; ++u) c0[u] = M::mma(v0[u][i], tw[i], c0[u]);
+    if (cok) {
+      if (r0 + STEP <= rows) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pc[r0 + 16 * u + M::drow(lane, i)] = c0[u][i];
+      } else {
+#pragma unroll
+        for (int u = 0; u < RT; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 16 * u + M::drow(lane, i);
+            if (r < rows) pc[r] = c0[u][i];
+          }
+      }
+    }
+  }
+}
+
+template <class T, int NS>
+__device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T* t_out, T* Ts, T* Rs, T* tau_s) {
+  typedef MT<T> M;
+  typedef typename M::acc_t acc_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n16 = lane & 15;
+#ifdef CORRLA_HH_TIMING
+  long long tacc[4] = {0, 0, 0, 0}, tlw[2] = {0, 0}, tprev = clock64();
+#define HH_TICK(i) { const long long tn = clock64(); tacc[i] += tn - tprev; tprev = tn; }
+#else
+#define HH_TICK(i)
+#endif
+  for (int j0 = 0, pi = 0; j0 < l; j0 += kWyNb, ++pi) {
+    const int nbk = min(kWyNb, l - j0), cend = j0 + nbk;
+    HH_TICK(3)
+    // (a) reflectors of the block
+    T x[NS];
+    {
+      const T* mc = P + (size_t)min(j0 + wave, l - 1) * RP;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int r = lane + 64 * i;
+        const T val = mc[min(r, rows - 1)];
+        x[i] = r < rows ? val : (T)0;
+      }
+    }
+    for (int jj = 0; jj < nbk; ++jj) {
+      const int j = j0 + jj;
+      T* cj = P + (size_t)j * RP;
+      if (wave == jj) {
+        T s2 = (T)0, xs = x[0];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const int r = lane + 64 * i;
+          s2 += r > j ? x[i] * x[i] : (T)0;
+          if (i > 0) xs = (j >> 6) == i ? x[i] : xs;
+        }
+        const T sigma = hh_wave_sum(s2);
+        const T alpha = hh_readlane(xs, j & 63);  // the diagonal entry: slice j / 64, lane j % 64
+        T tau = (T)0, beta = alpha, scale = (T)0;
+        if (sigma > (T)0) {  // LAPACK xLARFG
+          beta = -copysign(hh_sqrt(alpha * alpha + sigma), alpha);
+          tau = (beta - alpha) * hh_rcp(beta);
+          scale = hh_rcp(alpha - beta);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const int r = lane + 64 * i;
+          if (r < rows) cj[r] = r > j ? x[i] * scale : (r == j ? beta : x[i]);
+        }
+        if (lane == 0) {
+          tau_s[jj] = tau;
+          tau_out[j] = tau;
+        }
+      }
+      hh_lds_barrier();
+      if (wave > jj && wave < nbk) {
+        T vf[NS];
+        T d = (T)0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const int r = lane + 64 * i;
+          const T val = cj[min(r, rows - 1)];
+          vf[i] = (r < rows && r > j) ? val : (r == j ? (T)1 : (T)0);
+          d += vf[i] * x[i];
+        }
+        const T w = tau_s[jj] * hh_wave_sum(d);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] -= w * vf[i];
+      }
+    }
+    if (tid >= nbk && tid < kWyNb) tau_s[tid] = (T)0;
+    hh_lds_barrier();
+    HH_TICK(0)
+    // clean V in place for the MFMA phases: the R entries of the 16 x 16 diagonal block are parked in Rs and come back
+    // when the next block is parked (or after the last block); rows above j0 are never read by this block's products
+    if (tid < kWyNb * kWyNb) {
+      const int ra = tid & 15, cb = tid >> 4;
+      if (ra <= cb) {
+        if (j0 > 0) P[(size_t)(j0 - kWyNb + cb) * RP + (j0 - kWyNb + ra)] = Rs[cb * kWyNb + ra];
+        if (cb < nbk) {
+          T* e = P + (size_t)(j0 + cb) * RP + (j0 + ra);
+          Rs[cb * kWyNb + ra] = *e;
+          *e = ra == cb ? (T)1 : (T)0;
+        }
+      }
+    }
+    hh_lds_barrier();
+    // (b) T of the block on the last wave (G = V^T V by one MFMA chain, then the xLARFT recurrence with lane i = row i),
+    //     while (c1) the other waves take W = V^T A for their trailing tiles (at most 8 tiles: the last wave has none)
+    const int ntile = (l - cend + 15) / 16;
+    acc_t w = {0, 0, 0, 0};
+    const int cc = cend + 16 * wave + n16;
+    const bool cok = wave < ntile && cc < l;
+    T* pc = P + (size_t)min(cc, l - 1) * RP;
+    const T* vcol = P + (size_t)min(j0 + n16, cend - 1) * RP;  // this lane's column of V in the V^T products
+    if (wave == kHhWaves - 1) {
+      const acc_t acc = wy_kdot<T>(vcol, vcol, j0, rows, g);
+#ifdef CORRLA_HH_TIMING
+      const long long tg1 = clock64();
+      tlw[0] += tg1 - tprev;  // on the last wave: the Gram chain
+#endif
+      // xLARFT recurrence, lane i = row i of T: T(0:j, j) = -tau_j T(0:j, 0:j) G(0:j, j); G(k, j) sits in D register
+      // WyD::reg(k) of lane 16 WyD::grp(k) + j and is broadcast through a scalar register
+      T trow[kWyNb];
+#pragma unroll
+      for (int j = 0; j < kWyNb; ++j) {
+        T a2 = (T)0;
+#pragma unroll
+        for (int kx = 0; kx < j; ++kx) a2 += trow[kx] * hh_readlane(acc[WyD<T>::reg(kx)], 16 * WyD<T>::grp(kx) + j);
+        const T tj = tau_s[j];
+        trow[j] = lane == j ? tj : (lane < j ? -tj * a2 : (T)0);
+      }
+      if (lane < kWyNb) {
+#pragma unroll
+        for (int j = 0; j < kWyNb; ++j) {
+          Ts[lane * kWyNb + j] = trow[j];
+          t_out[(size_t)pi * kWyNb * kWyNb + lane * kWyNb + j] = trow[j];
+        }
+      }
+#ifdef CORRLA_HH_TIMING
+      tlw[1] += clock64() - tg1;  // on the last wave: the recurrence and the stores of T
+#endif
+    } else if (wave < ntile) {
+      // (a tile column past l reads column l - 1: finite values whose results are never stored)
+      w = wy_kdot<T>(vcol, (const T*)pc, j0, rows, g);
+    }
+    hh_lds_barrier();
+    HH_TICK(1)
+    // (c2) TW = T^T W and A -= V TW
+    if (wave < ntile) {
+      acc_t tw = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tw = M::mma(Ts[M::drow(lane, i) * kWyNb + n16], w[i], tw);
+      wy_update<T>(pc, cok, (const T*)P, (int64_t)RP, j0, cend, rows, tw, lane);
+    }
+    hh_lds_barrier();
+    HH_TICK(2)
+  }
+  if (tid < kWyNb * kWyNb) {
+    const int ra = tid & 15, cb = tid >> 4, jl = (hh_wy_panels(l) - 1) * kWyNb;
+    if (ra <= cb && jl + cb < l) P[(size_t)(jl + cb) * RP + (jl + ra)] = Rs[cb * kWyNb + ra];
+  }
+  hh_lds_barrier();
+#ifdef CORRLA_HH_TIMING
+  if (blockIdx.x == 0 && tid == 64 * (kHhWaves - 1)) printf("  last wave: gram %lld  recurrence %lld\n", tlw[0], tlw[1]);
+  if (blockIdx.x == 0 && tid == 0)
+    printf("hh_wy_factor rows %d l %d: reflectors %lld  T+W %lld  update %lld  other %lld cycles\n", rows, l, tacc[0], tacc[1], tacc[2],
+           tacc[3]);
+#endif
+}
+
+// P <- H_0 ... H_{l-1} P with the blocks' V (global, leading dimension ldv) and T (global, 256 per block)
+template <class T>
+__device__ void hh_wy_apply_panel(T* P, int RP, int rows, int l, const T* __restrict__ V, int64_t ldv, const T* __restrict__ t_in) {
+  typedef MT<T> M;
+  typedef typename M::acc_t acc_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n16 = lane & 15;
+  const int ntile = (l + 15) / 16;
+  for (int t = wave; t < ntile; t += kHhWaves) {
+    const int cc = 16 * t + n16;
+    const bool cok = cc < l;
+    T* pc = P + (size_t)min(cc, l - 1) * RP;
+    for (int pi = hh_wy_panels(l) - 1; pi >= 0; --pi) {
+      const int j0 = pi * kWyNb, cend = min(j0 + kWyNb, l);
+      const T* tp = t_in + (size_t)pi * kWyNb * kWyNb;
+      const T* vcol = V + (int64_t)min(j0 + n16, cend - 1) * ldv;
+      const acc_t w = wy_kdot<T>(vcol, (const T*)pc, j0, rows, g);
+      acc_t tw = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tw = M::mma(tp[n16 * kWyNb + M::drow(lane, i)], w[i], tw);  // T W
+      wy_update<T>(pc, cok, V, ldv, j0, cend, rows, tw, lane);
+    }
+  }
+}
+
 // ---- up sweep -----------------------------------------------------------------------------------------------------
 // leaves: panel i = rows [row0(i), row0(i + 1)) of y (column-major, ld ldy).  Reflectors -> v (same layout as y),
 // tau -> tau[i * l ..], R -> rout[i * l * l ..] (l x l column-major, zeros below the diagonal).
-template <class T>
+template <class T, bool WY>
 __global__ __launch_bounds__(kHhThreads) void hh_leaf_factor_kernel(const T* __restrict__ y, int64_t ldy, int64_t m, int l,
                                                                     int nleaf, T* __restrict__ v, int64_t ldv, T* tau,
-                                                                    T* rout) {
+                                                                    T* rout, T* tbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* P = (T*)smem;
+  T* P = (T*)smem + (WY ? kWyExtra : 0);
   const int node = blockIdx.x;
   const int64_t r0 = hh_leaf_row0(m, nleaf, node);
   const int rows = (int)(hh_leaf_row0(m, nleaf, node + 1) - r0);
@@ -232,10 +579,16 @@ __global__ __launch_bounds__(kHhThreads) void hh_leaf_factor_kernel(const T* __r
     P[(size_t)c * RP + r] = y[(int64_t)c * ldy + r0 + r];
   }
   __syncthreads();
-  hh_factor_panel<T, kHhMaxRowsPerLane, false>(P, RP, rows, l, tau + (size_t)node * l);
+  if constexpr (WY)
+    hh_wy_factor_panel<T, kHhMaxRowsPerLane>(P, RP, rows, l, tau + (size_t)node * l,
+                                             tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb, (T*)smem,
+                                             (T*)smem + kWyNb * kWyNb, (T*)smem + 2 * kWyNb * kWyNb);
+  else
+    hh_factor_panel<T, kHhMaxRowsPerLane, false>(P, RP, rows, l, tau + (size_t)node * l);
   for (int idx = threadIdx.x; idx < rows * l; idx += kHhThreads) {
     const int c = idx / rows, r = idx - c * rows;
-    v[(int64_t)c * ldv + r0 + r] = P[(size_t)c * RP + r];
+    const T pv = P[(size_t)c * RP + r];
+    v[(int64_t)c * ldv + r0 + r] = WY ? (r > c ? pv : (r == c ? (T)1 : (T)0)) : pv;  // blocked form: clean reflectors
   }
   T* ro = rout + (size_t)node * l * l;
   for (int idx = threadIdx.x; idx < l * l; idx += kHhThreads) {
@@ -246,11 +599,11 @@ __global__ __launch_bounds__(kHhThreads) void hh_leaf_factor_kernel(const T* __r
 
 // inner level: node t combines rin[2 t] and rin[2 t + 1] (an unpaired last R is passed through, tau = 0).
 // Reflectors -> v[t] (2 l x l, ld 2 l), tau -> tau[t * l ..], R -> rout[t].
-template <class T>
+template <class T, bool WY>
 __global__ __launch_bounds__(kHhThreads) void hh_tree_factor_kernel(const T* __restrict__ rin, int n_in, int l, T* __restrict__ v,
-                                                                    T* tau, T* rout) {
+                                                                    T* tau, T* rout, T* tbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* P = (T*)smem;
+  T* P = (T*)smem + (WY ? kWyExtra : 0);
   const int node = blockIdx.x;
   const int a = 2 * node, b = 2 * node + 1;
   T* ro = rout + (size_t)node * l * l;
@@ -266,11 +619,17 @@ __global__ __launch_bounds__(kHhThreads) void hh_tree_factor_kernel(const T* __r
     P[(size_t)c * RP + l + r] = rin[(size_t)b * l * l + idx];
   }
   __syncthreads();
-  hh_factor_panel<T, kHhTriSlices, true>(P, RP, rows, l, tau + (size_t)node * l);
+  if constexpr (WY)
+    hh_wy_factor_panel<T, kHhMaxRowsPerLane>(P, RP, rows, l, tau + (size_t)node * l,
+                                             tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb, (T*)smem,
+                                             (T*)smem + kWyNb * kWyNb, (T*)smem + 2 * kWyNb * kWyNb);
+  else
+    hh_factor_panel<T, kHhTriSlices, true>(P, RP, rows, l, tau + (size_t)node * l);
   T* vo = v + (size_t)node * rows * l;
   for (int idx = threadIdx.x; idx < rows * l; idx += kHhThreads) {
     const int c = idx / rows, r = idx - c * rows;
-    vo[idx] = P[(size_t)c * RP + r];
+    const T pv = P[(size_t)c * RP + r];
+    vo[idx] = WY ? (r > c ? pv : (r == c ? (T)1 : (T)0)) : pv;
   }
   for (int idx = threadIdx.x; idx < l * l; idx += kHhThreads) {
     const int c = idx / l, r = idx - c * l;
@@ -281,9 +640,10 @@ __global__ __launch_bounds__(kHhThreads) void hh_tree_factor_kernel(const T* __r
 // ---- down sweep ---------------------------------------------------------------------------------------------------
 // inner level: node t turns its coefficient block cin[t] (l x l; the identity when cin == nullptr: the root) into
 // the blocks of its children cout[2 t], cout[2 t + 1].
-template <class T>
+template <class T, bool WY>
 __global__ __launch_bounds__(kHhThreads) void hh_tree_apply_kernel(const T* __restrict__ cin, const T* __restrict__ v,
-                                                                   const T* __restrict__ tau, int n_children, int l, T* cout) {
+                                                                   const T* __restrict__ tau, int n_children, int l, T* cout,
+                                                                   const T* __restrict__ tbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* P = (T*)smem;
   const int node = blockIdx.x;
@@ -302,7 +662,11 @@ __global__ __launch_bounds__(kHhThreads) void hh_tree_apply_kernel(const T* __re
     P[(size_t)c * RP + l + r] = (T)0;
   }
   __syncthreads();
-  hh_apply_panel<T, kHhTriSlices, true>(P, RP, rows, l, v + (size_t)node * rows * l, (int64_t)rows, tau + (size_t)node * l);
+  if constexpr (WY)
+    hh_wy_apply_panel<T>(P, RP, rows, l, v + (size_t)node * rows * l, (int64_t)rows,
+                         tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb);
+  else
+    hh_apply_panel<T, kHhTriSlices, true>(P, RP, rows, l, v + (size_t)node * rows * l, (int64_t)rows, tau + (size_t)node * l);
   __syncthreads();
   for (int idx = threadIdx.x; idx < l * l; idx += kHhThreads) {
     const int c = idx / l, r = idx - c * l;
@@ -312,10 +676,10 @@ __global__ __launch_bounds__(kHhThreads) void hh_tree_apply_kernel(const T* __re
 }
 
 // leaves: rows of Q = H_0 ... H_{l-1} [cin[i]; 0]  (cin == nullptr: a single leaf, coefficient block = identity)
-template <class T>
+template <class T, bool WY>
 __global__ __launch_bounds__(kHhThreads) void hh_leaf_apply_kernel(const T* __restrict__ cin, const T* __restrict__ v, int64_t ldv,
                                                                    const T* __restrict__ tau, int64_t m, int l, int nleaf,
-                                                                   T* __restrict__ q, int64_t ldq) {
+                                                                   T* __restrict__ q, int64_t ldq, const T* __restrict__ tbuf) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* P = (T*)smem;
   const int node = blockIdx.x;
@@ -329,7 +693,10 @@ __global__ __launch_bounds__(kHhThreads) void hh_leaf_apply_kernel(const T* __re
     P[(size_t)c * RP + r] = val;
   }
   __syncthreads();
-  hh_apply_panel<T, kHhMaxRowsPerLane, false>(P, RP, rows, l, v + r0, ldv, tau + (size_t)node * l);
+  if constexpr (WY)
+    hh_wy_apply_panel<T>(P, RP, rows, l, v + r0, ldv, tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb);
+  else
+    hh_apply_panel<T, kHhMaxRowsPerLane, false>(P, RP, rows, l, v + r0, ldv, tau + (size_t)node * l);
   __syncthreads();
   for (int idx = threadIdx.x; idx < rows * l; idx += kHhThreads) {
     const int c = idx / rows, r = idx - c * rows;
