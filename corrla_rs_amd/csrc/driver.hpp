@@ -226,7 +226,7 @@ struct RsvdDriver {
     if (hh_short_shards_ < 0) hh_short_shards_ = (int)dev.allreduce_sum_host(m_local_ < y.cols ? 1 : 0);
     return hh_short_shards_ == 0;
   }
-  // One column panel (at most 138 columns in f32 / 97 in f64: 2 l x l must fit in LDS): TSQR over this rank's rows.
+  // One column panel (at most 142 columns in f32 / 99 in f64: 2 l x l must fit in LDS): TSQR over this rank's rows.
   // Row-sharded: the P root R factors are stacked (one all-reduce of a zero-padded P l x l buffer = an all-gather), every
   // rank takes the thin-Q of the stack redundantly (same arithmetic -> same bits) and feeds its own l x l block of it
   // into the down sweep:  Y = diag(Q_r) [R_r] = diag(Q_r) Q' R  =>  Q = [Q_r C_r].  (R-factor exchange.)

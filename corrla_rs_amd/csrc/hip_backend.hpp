@@ -734,7 +734,7 @@ class HipDev {
     HhState<T> h = householder_up(y, tmp);
     householder_down(h, y, tmp);
   }
-  // widest panel one workgroup can hold: 138 (f32) / 97 (f64)
+  // widest panel one workgroup can hold: 142 (f32) / 99 (f64)
   template <class T>
   int householder_max_width() const {
     int w = 1;

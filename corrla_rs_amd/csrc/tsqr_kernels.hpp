@@ -11,9 +11,12 @@
 //          l x l coefficient blocks, every inner node turns its coefficient block into two, every leaf turns its
 //          block into its rows of Q.  In this direction a wave owns its columns for the whole panel, so the
 //          apply loop needs no barriers at all.
+// Two panel codes: the unblocked one (hh_factor_panel / hh_apply_panel: every reflector applied to the whole trailing
+// panel by the VALU) and the blocked compact-WY one (hh_wy_*: reflector steps inside 16-column blocks, trailing update
+// and down sweep on the MFMA units), selected per context (CORRLA_HH_WY, default blocked).
 // A Householder thin-Q is orthonormal whatever the rank of the sketch (tau = 0 for a column that is already reduced),
 // which is exactly the behaviour of the reference on rank-deficient inputs.  One panel (2 l x l) must fit in the
-// 160 KB LDS of a CU: l <= 138 (f32) / l <= 97 (f64).
+// 160 KB LDS of a CU: l <= 142 (f32) / l <= 99 (f64).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -236,6 +239,9 @@ __device__ void hh_apply_panel(T* P, int RP, int rows, int l, const T* __restric
 constexpr int kWyNb = 16;
 constexpr int kWyPipe = 8;      // k-steps whose operand loads are issued before their MFMAs
 constexpr int kWyRowTiles = 3;  // 16-row tiles of the rank-16 update in flight together
+// down sweep: V streams from global memory (L1 / L2)
+constexpr int kWyApplyPipe = 8;   // (16 / 6 measured slower: the masked last trip grows with the depth)
+constexpr int kWyApplyRowTiles = 3;
 static_assert(kHhWaves >= kWyNb, "one wave per column of a block");
 static_assert(kHhMaxRowsPerLane * 64 / 2 / 16 + 1 <= kHhWaves - 1, "trailing tiles of a block: one wave each, the last wave builds T");
 constexpr int kWyExtra = 2 * kWyNb * kWyNb + kWyNb;  // Ts, Rs (parked diagonal block), tau_s (elements) in front of the panel
@@ -293,10 +299,11 @@ __device__ __forceinline__ double hh_readlane(double x, int l) {
 // issued together before their MFMAs; whole trips read through one address with immediate offsets (no clamps, no
 // masks) and only the last partial trip is masked.  (Prefetching the next trip across the MFMAs measured slower: the
 // register copies and the second accumulator cost more than the exposed LDS latency.)
-template <class T>
+template <class T, int PIPE>
 __device__ __forceinline__ typename MT<T>::acc_t wy_kdot(const T* acol, const T* bcol, int k0, int rows, int g) {
   typedef MT<T> M;
   typedef typename M::acc_t acc_t;
+  constexpr int kWyPipe = PIPE;  // (shadows the default depth)
   auto load = [&](int kk, T(&av)[kWyPipe], T(&bv)[kWyPipe]) {
     if (kk + 4 * kWyPipe <= rows) {
       const T* qa = acol + kk + g;
@@ -328,12 +335,12 @@ __device__ __forceinline__ typename MT<T>::acc_t wy_kdot(const T* acol, const T*
 
 // This lane's tile column pc (rows [j0, rows)) -= V(:, block) TW: 16-row tiles, kWyRowTiles per trip (loads, MFMAs,
 // stores); whole trips unmasked, the last partial trip masked.
-template <class T>
+template <class T, int RT>
 __device__ __forceinline__ void wy_update(T* pc, bool cok, const T* V, int64_t ldv, int j0, int cend, int rows,
                                           typename MT<T>::acc_t tw, int lane) {
   typedef MT<T> M;
   typedef typename M::acc_t acc_t;
-  constexpr int RT = kWyRowTiles, STEP = 16 * RT;
+  constexpr int STEP = 16 * RT;
   const int n16 = lane & 15;
   const T* vc[4];
 #pragma unroll
@@ -482,7 +489,7 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
     T* pc = P + (size_t)min(cc, l - 1) * RP;
     const T* vcol = P + (size_t)min(j0 + n16, cend - 1) * RP;  // this lane's column of V in the V^T products
     if (wave == kHhWaves - 1) {
-      const acc_t acc = wy_kdot<T>(vcol, vcol, j0, rows, g);
+      const acc_t acc = wy_kdot<T, kWyPipe>(vcol, vcol, j0, rows, g);
 #ifdef CORRLA_HH_TIMING
       const long long tg1 = clock64();
       tlw[0] += tg1 - tprev;  // on the last wave: the Gram chain
@@ -510,7 +517,7 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
 #endif
     } else if (wave < ntile) {
       // (a tile column past l reads column l - 1: finite values whose results are never stored)
-      w = wy_kdot<T>(vcol, (const T*)pc, j0, rows, g);
+      w = wy_kdot<T, kWyPipe>(vcol, (const T*)pc, j0, rows, g);
     }
     hh_lds_barrier();
     HH_TICK(1)
@@ -519,7 +526,7 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
       acc_t tw = {0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 4; ++i) tw = M::mma(Ts[M::drow(lane, i) * kWyNb + n16], w[i], tw);
-      wy_update<T>(pc, cok, (const T*)P, (int64_t)RP, j0, cend, rows, tw, lane);
+      wy_update<T, kWyRowTiles>(pc, cok, (const T*)P, (int64_t)RP, j0, cend, rows, tw, lane);
     }
     hh_lds_barrier();
     HH_TICK(2)
@@ -552,11 +559,11 @@ __device__ void hh_wy_apply_panel(T* P, int RP, int rows, int l, const T* __rest
       const int j0 = pi * kWyNb, cend = min(j0 + kWyNb, l);
       const T* tp = t_in + (size_t)pi * kWyNb * kWyNb;
       const T* vcol = V + (int64_t)min(j0 + n16, cend - 1) * ldv;
-      const acc_t w = wy_kdot<T>(vcol, (const T*)pc, j0, rows, g);
+      const acc_t w = wy_kdot<T, kWyPipe>(vcol, (const T*)pc, j0, rows, g);
       acc_t tw = {0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 4; ++i) tw = M::mma(tp[n16 * kWyNb + M::drow(lane, i)], w[i], tw);  // T W
-      wy_update<T>(pc, cok, V, ldv, j0, cend, rows, tw, lane);
+      wy_update<T, kWyApplyRowTiles>(pc, cok, V, ldv, j0, cend, rows, tw, lane);
     }
   }
 }

@@ -65,7 +65,7 @@ typedef enum corrla_status {
 #define CORRLA_PCA_CENTER_COPY 0x4u
 /* Thin-Q of the sketch (`y_mat.qr().compute_thin_q()`, random_svd.rs:38,57) by Householder TSQR with an explicit Q
  * (row panels reduced in LDS, pairwise tree over the R factors, reflectors applied in reverse) instead of the default
- * CholeskyQR2.  One panel holds l = min(rank + n_oversamples, n) <= 138 (f32) / 97 (f64) columns; wider sketches go
+ * CholeskyQR2.  One panel holds l = min(rank + n_oversamples, n) <= 142 (f32) / 99 (f64) columns; wider sketches go
  * through column blocks of that width (projection against the finished blocks + panel, repeated).  On the row-sharded
  * entry points every rank reduces its rows, the root R factors are exchanged (one all-reduce of an nranks * l x l
  * buffer) and their stack is reduced redundantly; a call in which some shard has fewer than l rows keeps the default

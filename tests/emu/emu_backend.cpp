@@ -237,7 +237,8 @@ class EmuDev {
   // csrc/tsqr_kernels.hpp / HipDev::householder_thin_q, written with plain loops --------------------------------
   template <class T>
   bool householder_fits(int64_t l) const {
-    return l >= 1 && (size_t)((2 * l + 3) / 4 * 4) * (size_t)l * sizeof(T) + 64 <= (size_t)160 * 1024 && 2 * l <= 320;
+    // one 2 l x l panel plus the blocked form's 16 x 16 T / parked-R blocks and tau (528 elements) in 160 KB of LDS
+    return l >= 1 && (size_t)((2 * l + 3) / 4 * 4) * (size_t)l * sizeof(T) + 64 + 528 * sizeof(T) <= (size_t)160 * 1024 && 2 * l <= 320;
   }
   template <class T>
   static void hh_factor_panel(std::vector<T>& P, int rows, int l, T* tau) {  // P column-major rows x l

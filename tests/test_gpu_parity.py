@@ -560,7 +560,7 @@ def test_householder_tsqr_rsvd_on_the_golden_fixtures(ctx, name, dtype):
 @pytest.mark.parametrize("m,n,width,dtype", [(5000, 300, 138, np.float32), (20000, 200, 97, np.float64), (277, 150, 138, np.float32),
                                              (100000, 64, 32, np.float64), (1000, 40, 1, np.float32), (3001, 90, 33, np.float64)])
 def test_householder_tsqr_power_iter_q(ctx, m, n, width, dtype):
-    """Widest panels that fit in LDS (l = 138 f32 / 97 f64), a single leaf, odd panel counts, many panels: Q orthonormal
+    """Wide panels (l = 138 f32 / 97 f64; the widest that fit are 142 / 99), a single leaf, odd panel counts, many panels: Q orthonormal
     and spanning the oracle's Householder Q of the same sketch."""
     from oracle import rsvd_oracle as orc
     rng = np.random.default_rng(m + width)
@@ -599,10 +599,11 @@ def test_householder_tsqr_rank_deficient_and_fallbacks(ctx, torch, monkeypatch):
         ctx.rsvd(b, 10, 1, 5, qr="givens")
 
 
-@pytest.mark.parametrize("m,n,width,dtype", [(6000, 400, 139, np.float32), (6000, 400, 352, np.float32), (20000, 300, 98, np.float64),
-                                             (8000, 600, 266, np.float64), (400, 360, 352, np.float64)])
+@pytest.mark.parametrize("m,n,width,dtype", [(6000, 400, 142, np.float32), (6000, 400, 143, np.float32), (6000, 400, 352, np.float32),
+                                             (20000, 300, 99, np.float64), (20000, 300, 100, np.float64), (8000, 600, 266, np.float64),
+                                             (400, 360, 352, np.float64)])
 def test_householder_wider_than_one_panel_goes_through_column_blocks(ctx, m, n, width, dtype):
-    """l > 138 (f32) / 97 (f64) up to the library's 352: column blocks of at most one LDS panel, each the thin-Q of
+    """l > 142 (f32) / 99 (f64) up to the library's 352: column blocks of at most one LDS panel, each the thin-Q of
     (I - Q Q^T) Y_j repeated around the Householder panels until the overlap the panel saw was small.  Q orthonormal to
     O(eps) and spanning the oracle's Householder Q; orthonormal also for a sketch of rank 5 (random_svd.rs:38,57 has no
     width limit and no rank condition)."""
