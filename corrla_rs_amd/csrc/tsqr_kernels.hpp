@@ -294,13 +294,14 @@ __device__ __forceinline__ double hh_readlane(double x, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 
-// sum over rows [k0, rows) of A(r) B(r)^T contributions of an MFMA product whose operands are r-contiguous columns
+// w0 + sum over rows [k0, rows) of A(r) B(r)^T contributions of an MFMA product whose operands are r-contiguous columns
 // (acol / bcol: this lane's column; lane group g supplies row 4 s + g of step s).  kWyPipe steps per trip, their loads
 // issued together before their MFMAs; whole trips read through one address with immediate offsets (no clamps, no
 // masks) and only the last partial trip is masked.  (Prefetching the next trip across the MFMAs measured slower: the
 // register copies and the second accumulator cost more than the exposed LDS latency.)
 template <class T, int PIPE>
-__device__ __forceinline__ typename MT<T>::acc_t wy_kdot(const T* acol, const T* bcol, int k0, int rows, int g) {
+__device__ __forceinline__ typename MT<T>::acc_t wy_kdot(const T* acol, const T* bcol, int k0, int rows, int g,
+                                                         typename MT<T>::acc_t w0) {
   typedef MT<T> M;
   typedef typename M::acc_t acc_t;
   constexpr int kWyPipe = PIPE;  // (shadows the default depth)
@@ -323,7 +324,6 @@ __device__ __forceinline__ typename MT<T>::acc_t wy_kdot(const T* acol, const T*
       }
     }
   };
-  acc_t w0 = {0, 0, 0, 0};
   for (int kk = k0; kk < rows; kk += 4 * kWyPipe) {
     T a0[kWyPipe], b0[kWyPipe];
     load(kk, a0, b0);
@@ -333,10 +333,10 @@ __device__ __forceinline__ typename MT<T>::acc_t wy_kdot(const T* acol, const T*
   return w0;
 }
 
-// This lane's tile column pc (rows [j0, rows)) -= V(:, block) TW: 16-row tiles, kWyRowTiles per trip (loads, MFMAs,
+// This lane's tile column pc (rows [rbeg, rows)) -= V(:, block) TW: 16-row tiles, kWyRowTiles per trip (loads, MFMAs,
 // stores); whole trips unmasked, the last partial trip masked.
 template <class T, int RT>
-__device__ __forceinline__ void wy_update(T* pc, bool cok, const T* V, int64_t ldv, int j0, int cend, int rows,
+__device__ __forceinline__ void wy_update(T* pc, bool cok, const T* V, int64_t ldv, int j0, int cend, int rbeg, int rows,
                                           typename MT<T>::acc_t tw, int lane) {
   typedef MT<T> M;
   typedef typename M::acc_t acc_t;
@@ -366,7 +366,7 @@ __device__ __forceinline__ void wy_update(T* pc, bool cok, const T* V, int64_t l
         }
     }
   };
-  for (int r0 = j0; r0 < rows; r0 += STEP) {
+  for (int r0 = rbeg; r0 < rows; r0 += STEP) {
     acc_t c0[RT];
     T v0[RT][4];
     load(r0, c0, v0);
@@ -393,7 +393,11 @@ __device__ __forceinline__ void wy_update(T* pc, bool cok, const T* V, int64_t l
   }
 }
 
-template <class T, int NS>
+// TRI: the panel is two stacked upper triangles [R_a; R_b] (rows = 2 l).  Column j of V then lives in row j and rows
+// l .. l + j only (nothing else of a column is, or becomes, non-zero): a wave keeps the block's 16 top rows and the
+// bottom triangle's rows (NS - 1 slices) of its column, and the MFMA phases run over rows [j0, j0 + 16) and
+// [l, l + cend) instead of [j0, 2 l).
+template <class T, int NS, bool TRI>
 __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T* t_out, T* Ts, T* Rs, T* tau_s) {
   typedef MT<T> M;
   typedef typename M::acc_t acc_t;
@@ -406,6 +410,17 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
 #endif
   for (int j0 = 0, pi = 0; j0 < l; j0 += kWyNb, ++pi) {
     const int nbk = min(kWyNb, l - j0), cend = j0 + nbk;
+    // row held by (slice i, this lane); `rows` = none
+    auto rowof = [&](int i) -> int {
+      if constexpr (TRI) return i < NS - 1 ? l + lane + 64 * i : ((lane < kWyNb && j0 + lane < l) ? j0 + lane : rows);
+      return lane + 64 * i;
+    };
+    // TRI: slices of the bottom triangle this block's reflectors can touch (uniform) -- its rows below l + cend are, and
+    // stay, zero.  (Skipping the finished rows above the block in a dense panel measured slower: 193 -> 203 us.)
+    auto live = [&](int i) -> bool {
+      if constexpr (TRI) return i == NS - 1 || 64 * i < cend;
+      return true;
+    };
     HH_TICK(3)
     // (a) reflectors of the block
     T x[NS];
@@ -413,9 +428,12 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
       const T* mc = P + (size_t)min(j0 + wave, l - 1) * RP;
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int r = lane + 64 * i;
-        const T val = mc[min(r, rows - 1)];
-        x[i] = r < rows ? val : (T)0;
+        x[i] = (T)0;
+        if (live(i)) {
+          const int r = rowof(i);
+          const T val = mc[min(r, rows - 1)];
+          x[i] = r < rows ? val : (T)0;
+        }
       }
     }
     for (int jj = 0; jj < nbk; ++jj) {
@@ -425,12 +443,12 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
         T s2 = (T)0, xs = x[0];
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-          const int r = lane + 64 * i;
-          s2 += r > j ? x[i] * x[i] : (T)0;
-          if (i > 0) xs = (j >> 6) == i ? x[i] : xs;
+          const int r = rowof(i);
+          if (live(i)) s2 += r > j ? x[i] * x[i] : (T)0;
+          if (i > 0) xs = (TRI ? NS - 1 : (j >> 6)) == i ? x[i] : xs;
         }
         const T sigma = hh_wave_sum(s2);
-        const T alpha = hh_readlane(xs, j & 63);  // the diagonal entry: slice j / 64, lane j % 64
+        const T alpha = hh_readlane(xs, TRI ? jj : (j & 63));  // the diagonal entry: slice j / 64, lane j % 64 (TRI: top slice)
         T tau = (T)0, beta = alpha, scale = (T)0;
         if (sigma > (T)0) {  // LAPACK xLARFG
           beta = -copysign(hh_sqrt(alpha * alpha + sigma), alpha);
@@ -439,8 +457,8 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
         }
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-          const int r = lane + 64 * i;
-          if (r < rows) cj[r] = r > j ? x[i] * scale : (r == j ? beta : x[i]);
+          const int r = rowof(i);
+          if (live(i) && r < rows) cj[r] = r > j ? x[i] * scale : (r == j ? beta : x[i]);
         }
         if (lane == 0) {
           tau_s[jj] = tau;
@@ -453,14 +471,18 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
         T d = (T)0;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-          const int r = lane + 64 * i;
-          const T val = cj[min(r, rows - 1)];
-          vf[i] = (r < rows && r > j) ? val : (r == j ? (T)1 : (T)0);
-          d += vf[i] * x[i];
+          vf[i] = (T)0;
+          if (live(i)) {
+            const int r = rowof(i);
+            const T val = cj[min(r, rows - 1)];
+            vf[i] = (r < rows && r > j) ? val : (r == j ? (T)1 : (T)0);
+            d += vf[i] * x[i];
+          }
         }
         const T w = tau_s[jj] * hh_wave_sum(d);
 #pragma unroll
-        for (int i = 0; i < NS; ++i) x[i] -= w * vf[i];
+        for (int i = 0; i < NS; ++i)
+          if (live(i)) x[i] -= w * vf[i];
       }
     }
     if (tid >= nbk && tid < kWyNb) tau_s[tid] = (T)0;
@@ -488,8 +510,10 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
     const bool cok = wave < ntile && cc < l;
     T* pc = P + (size_t)min(cc, l - 1) * RP;
     const T* vcol = P + (size_t)min(j0 + n16, cend - 1) * RP;  // this lane's column of V in the V^T products
+    const int s1e = TRI ? min(j0 + kWyNb, l) : rows, s2e = l + cend;  // V is non-zero in rows [j0, s1e) (and [l, s2e))
     if (wave == kHhWaves - 1) {
-      const acc_t acc = wy_kdot<T, kWyPipe>(vcol, vcol, j0, rows, g);
+      acc_t acc = wy_kdot<T, kWyPipe>(vcol, vcol, j0, s1e, g, acc_t{0, 0, 0, 0});
+      if constexpr (TRI) acc = wy_kdot<T, kWyPipe>(vcol, vcol, l, s2e, g, acc);
 #ifdef CORRLA_HH_TIMING
       const long long tg1 = clock64();
       tlw[0] += tg1 - tprev;  // on the last wave: the Gram chain
@@ -517,7 +541,8 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
 #endif
     } else if (wave < ntile) {
       // (a tile column past l reads column l - 1: finite values whose results are never stored)
-      w = wy_kdot<T, kWyPipe>(vcol, (const T*)pc, j0, rows, g);
+      w = wy_kdot<T, kWyPipe>(vcol, (const T*)pc, j0, s1e, g, w);
+      if constexpr (TRI) w = wy_kdot<T, kWyPipe>(vcol, (const T*)pc, l, s2e, g, w);
     }
     hh_lds_barrier();
     HH_TICK(1)
@@ -526,7 +551,8 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
       acc_t tw = {0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 4; ++i) tw = M::mma(Ts[M::drow(lane, i) * kWyNb + n16], w[i], tw);
-      wy_update<T, kWyRowTiles>(pc, cok, (const T*)P, (int64_t)RP, j0, cend, rows, tw, lane);
+      wy_update<T, kWyRowTiles>(pc, cok, (const T*)P, (int64_t)RP, j0, cend, j0, s1e, tw, lane);
+      if constexpr (TRI) wy_update<T, kWyRowTiles>(pc, cok, (const T*)P, (int64_t)RP, j0, cend, l, s2e, tw, lane);
     }
     hh_lds_barrier();
     HH_TICK(2)
@@ -545,7 +571,7 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
 }
 
 // P <- H_0 ... H_{l-1} P with the blocks' V (global, leading dimension ldv) and T (global, 256 per block)
-template <class T>
+template <class T, bool TRI>
 __device__ void hh_wy_apply_panel(T* P, int RP, int rows, int l, const T* __restrict__ V, int64_t ldv, const T* __restrict__ t_in) {
   typedef MT<T> M;
   typedef typename M::acc_t acc_t;
@@ -559,11 +585,14 @@ __device__ void hh_wy_apply_panel(T* P, int RP, int rows, int l, const T* __rest
       const int j0 = pi * kWyNb, cend = min(j0 + kWyNb, l);
       const T* tp = t_in + (size_t)pi * kWyNb * kWyNb;
       const T* vcol = V + (int64_t)min(j0 + n16, cend - 1) * ldv;
-      const acc_t w = wy_kdot<T, kWyPipe>(vcol, (const T*)pc, j0, rows, g);
+      const int s1e = TRI ? min(j0 + kWyNb, l) : rows, s2e = l + cend;
+      acc_t w = wy_kdot<T, kWyApplyPipe>(vcol, (const T*)pc, j0, s1e, g, acc_t{0, 0, 0, 0});
+      if constexpr (TRI) w = wy_kdot<T, kWyApplyPipe>(vcol, (const T*)pc, l, s2e, g, w);
       acc_t tw = {0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 4; ++i) tw = M::mma(tp[n16 * kWyNb + M::drow(lane, i)], w[i], tw);  // T W
-      wy_update<T, kWyApplyRowTiles>(pc, cok, V, ldv, j0, cend, rows, tw, lane);
+      wy_update<T, kWyApplyRowTiles>(pc, cok, V, ldv, j0, cend, j0, s1e, tw, lane);
+      if constexpr (TRI) wy_update<T, kWyApplyRowTiles>(pc, cok, V, ldv, j0, cend, l, s2e, tw, lane);
     }
   }
 }
@@ -587,9 +616,9 @@ __global__ __launch_bounds__(kHhThreads) void hh_leaf_factor_kernel(const T* __r
   }
   __syncthreads();
   if constexpr (WY)
-    hh_wy_factor_panel<T, kHhMaxRowsPerLane>(P, RP, rows, l, tau + (size_t)node * l,
-                                             tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb, (T*)smem,
-                                             (T*)smem + kWyNb * kWyNb, (T*)smem + 2 * kWyNb * kWyNb);
+    hh_wy_factor_panel<T, kHhMaxRowsPerLane, false>(P, RP, rows, l, tau + (size_t)node * l,
+                                                    tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb, (T*)smem,
+                                                    (T*)smem + kWyNb * kWyNb, (T*)smem + 2 * kWyNb * kWyNb);
   else
     hh_factor_panel<T, kHhMaxRowsPerLane, false>(P, RP, rows, l, tau + (size_t)node * l);
   for (int idx = threadIdx.x; idx < rows * l; idx += kHhThreads) {
@@ -627,9 +656,9 @@ __global__ __launch_bounds__(kHhThreads) void hh_tree_factor_kernel(const T* __r
   }
   __syncthreads();
   if constexpr (WY)
-    hh_wy_factor_panel<T, kHhMaxRowsPerLane>(P, RP, rows, l, tau + (size_t)node * l,
-                                             tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb, (T*)smem,
-                                             (T*)smem + kWyNb * kWyNb, (T*)smem + 2 * kWyNb * kWyNb);
+    hh_wy_factor_panel<T, kHhTriSlices + 1, true>(P, RP, rows, l, tau + (size_t)node * l,
+                                                  tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb, (T*)smem,
+                                                  (T*)smem + kWyNb * kWyNb, (T*)smem + 2 * kWyNb * kWyNb);
   else
     hh_factor_panel<T, kHhTriSlices, true>(P, RP, rows, l, tau + (size_t)node * l);
   T* vo = v + (size_t)node * rows * l;
@@ -670,7 +699,7 @@ __global__ __launch_bounds__(kHhThreads) void hh_tree_apply_kernel(const T* __re
   }
   __syncthreads();
   if constexpr (WY)
-    hh_wy_apply_panel<T>(P, RP, rows, l, v + (size_t)node * rows * l, (int64_t)rows,
+    hh_wy_apply_panel<T, true>(P, RP, rows, l, v + (size_t)node * rows * l, (int64_t)rows,
                          tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb);
   else
     hh_apply_panel<T, kHhTriSlices, true>(P, RP, rows, l, v + (size_t)node * rows * l, (int64_t)rows, tau + (size_t)node * l);
@@ -701,7 +730,7 @@ __global__ __launch_bounds__(kHhThreads) void hh_leaf_apply_kernel(const T* __re
   }
   __syncthreads();
   if constexpr (WY)
-    hh_wy_apply_panel<T>(P, RP, rows, l, v + r0, ldv, tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb);
+    hh_wy_apply_panel<T, false>(P, RP, rows, l, v + r0, ldv, tbuf + (size_t)node * hh_wy_panels(l) * kWyNb * kWyNb);
   else
     hh_apply_panel<T, kHhMaxRowsPerLane, false>(P, RP, rows, l, v + r0, ldv, tau + (size_t)node * l);
   __syncthreads();
