@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <limits>
 #include <type_traits>
 
 #include "hip_kernels.hpp"  // MT<T>: the MFMA wrappers and their register layouts
@@ -450,8 +451,12 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
         const T sigma = hh_wave_sum(s2);
         const T alpha = hh_readlane(xs, TRI ? jj : (j & 63));  // the diagonal entry: slice j / 64, lane j % 64 (TRI: top slice)
         T tau = (T)0, beta = alpha, scale = (T)0;
-        if (sigma > (T)0) {  // LAPACK xLARFG
-          beta = -copysign(hh_sqrt(alpha * alpha + sigma), alpha);
+        // LAPACK xLARFG.  The hardware sqrt / rcp flush denormals: a column whose squared norm is below the smallest
+        // normal number (entries below ~1e-19 in f32 -- where sigma itself underflows) counts as already reduced
+        // (tau = 0, its sub-diagonal entries dropped) instead of producing 1 / 0.
+        const T n2 = alpha * alpha + sigma;
+        if (sigma > (T)0 && n2 >= std::numeric_limits<T>::min()) {
+          beta = -copysign(hh_sqrt(n2), alpha);
           tau = (beta - alpha) * hh_rcp(beta);
           scale = hh_rcp(alpha - beta);
         }

@@ -625,6 +625,26 @@ def test_householder_wider_than_one_panel_goes_through_column_blocks(ctx, m, n, 
     assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vo)) < (1e-9 if dtype == np.float64 else 1e-5)
 
 
+def test_householder_panels_survive_columns_of_denormal_size(ctx):
+    """The blocked panels take sqrt / reciprocals from the hardware approximations, which flush denormals: a trailing
+    column whose squared norm is denormal (a decaying f32 sketch after three un-orthonormalised power iterations) must
+    count as already reduced instead of producing 1 / 0 (found by tools/fuzz_parity.py, seed 62 case 23)."""
+    from oracle import rsvd_oracle as orc
+    rng = np.random.default_rng(23)
+    a = (rng.standard_normal((55, 392)) * (0.93 ** np.arange(392))).astype(np.float32)
+    om = rng.standard_normal((55, 8)).astype(np.float32)
+    u, s, vt = ctx.rsvd(a, 5, 3, 3, omega=om, qr="householder")
+    uo, so, vo = orc.random_svd(a.astype(np.float64), 5, 3, 3, omega=om.astype(np.float64))
+    assert np.all(np.isfinite(s)) and np.all(np.isfinite(u)) and np.all(np.isfinite(vt))
+    assert np.max(np.abs(s.ravel() - so.ravel())) < 2e-4 * so[0, 0]
+    # columns far below the normal range: every reflector of the panel sees a (sub)normal norm
+    tiny = (rng.standard_normal((600, 40)) * 1e-30).astype(np.float32)
+    tiny[:, 20:] *= 1e-12
+    q = ctx.power_iter(tiny, 30, 0, omega=rng.standard_normal((40, 30)).astype(np.float32), qr="householder")
+    assert np.all(np.isfinite(q))
+    assert np.max(np.abs(q.T.astype(np.float64) @ q - np.eye(30))) < 1e-5
+
+
 def test_householder_on_the_sharded_entry_point_world_size_1_rccl(torch, monkeypatch):
     """Cross-rank TSQR on a real one-rank RCCL communicator with every all-reduce issued (the stack of root R factors
     is the one R; the N = 2 exchange runs on the CPU through the same driver, tests/test_sharded_gloo.py): one panel
