@@ -54,30 +54,61 @@ def log(*a):
 
 def spawn_ranks(args):
     """--gpus N from a plain shell: start the N ranks as CHILD processes (this parent never initialises the GPU, so
-    nothing that has touched the GPU is ever exec'ed or forked) and relay rank 0's stdout."""
+    nothing that has touched the GPU is ever exec'ed or forked) and relay rank 0's stdout.  Every rank runs in its own
+    session; the parent polls them all: the first non-zero exit, the deadline, or a SIGTERM / SIGINT to the parent
+    (e.g. an outer `timeout`) ends the WHOLE group -- a rank that died must not leave its peers blocked in an RCCL
+    collective with the GPUs held, and a killed parent must not orphan them."""
+    import atexit
+    import signal
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)     # start_new_session: pid == process-group id
+                except (ProcessLookupError, PermissionError):
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass
+
+    def on_signal(signum, _frame):
+        kill_all()
+        os._exit(128 + signum)
+
+    atexit.register(kill_all)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, on_signal)
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CORRLA_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+                                      stdout=(None if r == 0 else subprocess.DEVNULL), start_new_session=True))
+    deadline = time.time() + float(os.environ.get("CORRLA_BENCH_TIMEOUT", "3000"))
     rc = 0
-    deadline = time.time() + 3000
-    for p in procs:
-        try:
-            rc = max(rc, abs(p.wait(timeout=max(1.0, deadline - time.time()))))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rc = max(rc, 124)
-    if rc:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            rc = abs(failed[0]) if abs(failed[0]) < 256 else 1
+            log(f"[bench] a rank exited with {failed[0]}: ending the other ranks")
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            rc = 124
+            log("[bench] deadline reached: ending the ranks")
+            break
+        time.sleep(0.05)
+    kill_all()
     sys.exit(rc)
 
 
@@ -189,6 +220,8 @@ def main():
         if int(os.environ.get("RANK", "0")) == 0:
             print(json.dumps({"dryrun": True, "world": int(os.environ.get("WORLD_SIZE", "1")), "config": args.config,
                               "master": os.environ.get("MASTER_ADDR")}), flush=True)
+        if os.environ.get("RANK", "0") == "0":   # rehearsal of a rank that is stuck (in a collective) while a peer dies
+            time.sleep(float(os.environ.get("CORRLA_BENCH_DRYRUN_SLEEP_RANK0", "0")))
         sys.exit(int(os.environ.get("CORRLA_BENCH_DRYRUN_RC", "0")) if os.environ.get("RANK") == "1" else 0)
 
     import torch

@@ -176,11 +176,14 @@ class Context:
         if a.device.index != self.device:
             raise ValueError(f"tensor is on {a.device}, context is on cuda:{self.device}")
         m, n = a.shape
-        if m == 0 or n == 0:
+        # an EMPTY shard (no rows; no columns with shard="cols") is legal on the sharded entry point: the rank takes part
+        # in the collectives with zero contributions and gets a 0-row (0-column) block of the sharded factor
+        empty_shard = sharded and ((n == 0 and m > 0) if shard_cols else (m == 0 and n > 0))
+        if (m == 0 or n == 0) and not empty_shard:
             raise ValueError("a_mat must be non-empty")
         if any(s < 0 for s in a.stride()):
             a = a.contiguous()
-        rs, cs = a.stride()
+        rs, cs = (max(n, 1), 1) if empty_shard else a.stride()
         suf = "f32" if a.dtype == torch.float32 else "f64"
         nt = (m if shard_cols else n) if sharded else min(m, n)
         l = min(k + max(p, 0), nt)

@@ -40,6 +40,7 @@ inline RunOpts parse_opts(const corrla_opts* o, bool dev_ptrs) {
   r.qr_householder = qr_env && std::strcmp(qr_env, "householder") == 0;
   const char* fu_env = std::getenv("CORRLA_POWER_FUSED");
   r.power_fused = fu_env && std::atoi(fu_env) != 0;
+  if (const char* pz = std::getenv("CORRLA_TEST_POISON_CORE")) r.poison_core = std::atoi(pz);  // test hook, see RunOpts
   if (!o) return r;
   if (o->struct_size != sizeof(corrla_opts)) throw Error(ST_EINVAL, "corrla_opts.struct_size mismatch");
   // seed: used as given when it is non-zero or CORRLA_SEED_EXPLICIT is set (so 0 is a usable seed); otherwise every
@@ -136,58 +137,113 @@ template <class Dev, class T>
 inline void rsvd_entry(Dev& dev, bool host_ptrs, bool sharded, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs,
                        int64_t rank, int64_t n_iter, int64_t n_oversamples, const corrla_opts* opts, T* u, int64_t ldu,
                        T* s, T* vt, int64_t ldvt, Timings* tm_out, bool profile) {
-  if (!u || !s || !vt) throw Error(ST_EINVAL, "output pointer is NULL");
-  validate_matrix(a, m, n, rs, cs);
   // Sharded calls: the LONG side of the global matrix is split over the ranks.  Default: row shards of a tall matrix
   // (local block m_local x n).  CORRLA_SHARD_COLS: column shards of a FAT matrix (local block m x n_local): the
   // tall view of random_svd.rs:69-74 is then A^T, whose row shard is this block transposed -- a stride swap, no copy.
   const bool shard_cols = sharded && opts && (opts->flags & CORRLA_SHARD_COLS) != 0;
-  if (!sharded && opts && (opts->flags & CORRLA_SHARD_COLS)) throw Error(ST_EINVAL, "CORRLA_SHARD_COLS is only valid for sharded entry points");
-  const int64_t short_side = shard_cols ? m : n;
-  if (sharded) {
-    if (rank < 1 || rank > short_side) throw Error(ST_EINVAL, "rank must be in [1, short side] for the sharded path");
-    if (n_iter < 0 || n_oversamples < 0) throw Error(ST_EINVAL, "n_iter and n_oversamples must be >= 0");
-    if (dev.nranks() < 1) throw Error(ST_ECOMM, "communicator not initialised");
-  } else {
-    validate_rank(m, n, rank, n_iter, n_oversamples);
-  }
-  if (ldu < m) throw Error(ST_EINVAL, "ldu < m");
-  if (ldvt < rank) throw Error(ST_EINVAL, "ldvt < rank");
-  RunOpts ro = parse_opts(opts, !host_ptrs);
-  ro.sharded = sharded;
-  if (!ro.seed_explicit && !ro.omega) ro.seed = dev.fresh_seed(/*rank_invariant=*/sharded);
-  dev.begin_call();
-  TallA<T> ta = shard_cols ? stage_input<Dev, T>(dev, host_ptrs, a, n, m, cs, rs, true)
-                           : stage_input<Dev, T>(dev, host_ptrs, a, m, n, rs, cs, sharded);
-  const bool fat = sharded ? shard_cols : m < n;
+  // An EMPTY shard (m_local == 0 rows, or n_local == 0 columns with CORRLA_SHARD_COLS) is legal on the sharded entry
+  // points -- more ranks than row blocks, ragged partitions: the rank takes part in every collective with zero
+  // contributions (its block is replaced by ONE zero row of the tall view, which adds nothing to any sum) and writes
+  // no row of the sharded output factor.
+  const bool empty_shard = sharded && m >= 0 && n >= 0 && (shard_cols ? (n == 0 && m >= 1) : (m == 0 && n >= 1));
   const int64_t k = rank;
-  const int64_t l = std::min<int64_t>(rank + n_oversamples, ta.nt);  // random_svd.rs:77
-  if (ro.omega && ro.omega_ld < ta.nt) throw Error(ST_EINVAL, "omega_ld < min(m, n)");
-  RsvdDriver<Dev, T> drv(dev, profile);
-  // Tall input, device pointers: the m x k factor U is produced directly in the caller's buffer (column-major, ldu)
-  // -- no staging copy of the largest output.
-  const bool u_in_place = !fat && !host_ptrs;
-  Skinny<T> ut;
-  if (u_in_place) {
-    ut.p = u;
-    ut.rows = ta.mt;
-    ut.cols = k;
-    ut.ld = ldu;
-    ut.cols_alloc = k;
-    ut.external = true;
+  RunOpts ro;
+  TallA<T> ta;
+  bool fat = false, u_in_place = false;
+  int64_t l = 0;
+  Skinny<T> ut, vtall;
+  T* s_dev = nullptr;
+  bool begun = false;
+  // Everything that can fail on ONE rank only (arguments, staging, workspace) happens before the first collective;
+  // on the sharded entry points its outcome is then agreed by one small all-reduce, so that a rank-local failure ends
+  // the call on every rank instead of stranding the peers in a collective (Dev::sharded_handshake).
+  auto prepare = [&] {
+    // (an empty shard has no rows of its sharded output factor: that pointer may be NULL)
+    if ((!u && !(empty_shard && !shard_cols)) || !s || (!vt && !(empty_shard && shard_cols)))
+      throw Error(ST_EINVAL, "output pointer is NULL");
+    if (!empty_shard) validate_matrix(a, m, n, rs, cs);
+    if (!sharded && opts && (opts->flags & CORRLA_SHARD_COLS)) throw Error(ST_EINVAL, "CORRLA_SHARD_COLS is only valid for sharded entry points");
+    const int64_t short_side = shard_cols ? m : n;
+    if (sharded) {
+      if (rank < 1 || rank > short_side) throw Error(ST_EINVAL, "rank must be in [1, short side] for the sharded path");
+      if (n_iter < 0 || n_oversamples < 0) throw Error(ST_EINVAL, "n_iter and n_oversamples must be >= 0");
+    } else {
+      validate_rank(m, n, rank, n_iter, n_oversamples);
+    }
+    if (ldu < m) throw Error(ST_EINVAL, "ldu < m");
+    if (ldvt < rank) throw Error(ST_EINVAL, "ldvt < rank");
+    ro = parse_opts(opts, !host_ptrs);
+    ro.sharded = sharded;
+    if (!ro.seed_explicit && !ro.omega) ro.seed = dev.fresh_seed(/*rank_invariant=*/sharded);
+    dev.begin_call();
+    begun = true;
+    if (empty_shard) {
+      const int64_t nt = short_side, ldp = round_up(nt, kLdPad);
+      T* zrow = (T*)dev.alloc_bytes((size_t)ldp * sizeof(T));
+      dev.memset_zero(zrow, (size_t)ldp * sizeof(T));
+      ta.mt = 1;
+      ta.nt = nt;
+      ta.row_major = true;
+      ta.mem.p = zrow;
+      ta.mem.rows = 1;
+      ta.mem.cols = nt;
+      ta.mem.ld = ldp;
+      ta.mem.cols_readable = ldp;
+    } else {
+      ta = shard_cols ? stage_input<Dev, T>(dev, host_ptrs, a, n, m, cs, rs, true)
+                      : stage_input<Dev, T>(dev, host_ptrs, a, m, n, rs, cs, sharded);
+    }
+    fat = sharded ? shard_cols : m < n;
+    l = std::min<int64_t>(rank + n_oversamples, ta.nt);  // random_svd.rs:77
+    if (ro.omega && ro.omega_ld < ta.nt) throw Error(ST_EINVAL, "omega_ld < min(m, n)");
+    // Tall input, device pointers: the m x k factor U is produced directly in the caller's buffer (column-major, ldu)
+    // -- no staging copy of the largest output.
+    u_in_place = !fat && !host_ptrs && !empty_shard;
+    if (u_in_place) {
+      ut.p = u;
+      ut.rows = ta.mt;
+      ut.cols = k;
+      ut.ld = ldu;
+      ut.cols_alloc = k;
+      ut.external = true;
+    } else {
+      ut = dev.template alloc_skinny<T>(ta.mt, k);
+    }
+    vtall = dev.template alloc_skinny<T>(ta.nt, k);
+    s_dev = dev.template alloc_scalar<T>((int)k);
+  };
+  if (!sharded) {
+    prepare();
   } else {
-    ut = dev.template alloc_skinny<T>(ta.mt, k);
+    if (dev.nranks() < 1) throw Error(ST_ECOMM, "communicator not initialised");
+    int local = ST_OK;
+    std::string local_msg;
+    try {
+      prepare();
+    } catch (const Error& e) {
+      local = e.code;
+      local_msg = e.what();
+    } catch (const std::bad_alloc&) {
+      local = ST_ENOMEM;
+      local_msg = "host allocation failed";
+    }
+    if (!begun) dev.begin_call();
+    const int agreed = dev.sharded_handshake(local);
+    if (local != ST_OK) throw Error(local, local_msg);
+    if (agreed != ST_OK)
+      throw Error(agreed, "sharded call abandoned: another rank failed before the first collective (status " + std::to_string(agreed) +
+                              "); this rank's arguments were valid");
   }
-  Skinny<T> vtall = dev.template alloc_skinny<T>(ta.nt, k);
-  T* s_dev = dev.template alloc_scalar<T>((int)k);
+  RsvdDriver<Dev, T> drv(dev, profile);
+  if (empty_shard) drv.m_local_override_ = 0;  // the stand-in zero row is not a row of the matrix
   drv.random_svd_tall(ta, k, l, n_iter, ro, ut, s_dev, vtall, [&] {
     // random_svd.rs:96-109: tall -> (U, S, V^T); fat -> (V, S, U^T) of the transposed problem
     if (!fat) {
-      if (!u_in_place) dev.copy_out(ut, k, u, ldu, /*transpose=*/false, host_ptrs);
+      if (!u_in_place && !empty_shard) dev.copy_out(ut, k, u, ldu, /*transpose=*/false, host_ptrs);
       dev.copy_out(vtall, k, vt, ldvt, /*transpose=*/true, host_ptrs);
     } else {
       dev.copy_out(vtall, k, u, ldu, false, host_ptrs);
-      dev.copy_out(ut, k, vt, ldvt, true, host_ptrs);
+      if (!empty_shard) dev.copy_out(ut, k, vt, ldvt, true, host_ptrs);
     }
     dev.copy_values_out(s_dev, k, s, host_ptrs);
   });
@@ -210,23 +266,53 @@ template <class Dev, class T>
 inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t rank,
                       int64_t n_iter, int64_t n_oversamples, const corrla_opts* opts, T* means, T* s, T* comps,
                       int64_t ldc, Timings* tm_out, bool profile, bool sharded = false) {
-  if (!means || !s || !comps) throw Error(ST_EINVAL, "output pointer is NULL");
-  validate_matrix(x, m, n, rs, cs);
-  if (sharded) {
-    if (rank < 1 || rank > n) throw Error(ST_EINVAL, "rank must be in [1, n_dim] for the sample-sharded PCA");
-    if (n_iter < 0 || n_oversamples < 0) throw Error(ST_EINVAL, "n_iter and n_oversamples must be >= 0");
-    if (dev.nranks() < 1) throw Error(ST_ECOMM, "communicator not initialised");
+  RunOpts ro;
+  TallA<T> ta;
+  bool begun = false;
+  // what can fail on one rank only comes before the first collective and is agreed by the handshake (see rsvd_entry);
+  // an empty shard is not supported here (the centring has no zero-contribution stand-in): it fails validation, on
+  // every rank alike
+  auto prepare = [&] {
+    if (!means || !s || !comps) throw Error(ST_EINVAL, "output pointer is NULL");
+    validate_matrix(x, m, n, rs, cs);
+    if (sharded) {
+      if (rank < 1 || rank > n) throw Error(ST_EINVAL, "rank must be in [1, n_dim] for the sample-sharded PCA");
+      if (n_iter < 0 || n_oversamples < 0) throw Error(ST_EINVAL, "n_iter and n_oversamples must be >= 0");
+    } else {
+      validate_rank(m, n, rank, n_iter, n_oversamples);
+    }
+    if (ldc < rank) throw Error(ST_EINVAL, "ldc < rank");
+    ro = parse_opts(opts, !host_ptrs);
+    ro.sharded = sharded;
+    if (!ro.seed_explicit && !ro.omega) ro.seed = dev.fresh_seed(sharded);
+    dev.begin_call();
+    begun = true;
+    ta = stage_input<Dev, T>(dev, host_ptrs, x, m, n, rs, cs, sharded);
+  };
+  if (!sharded) {
+    prepare();
   } else {
-    validate_rank(m, n, rank, n_iter, n_oversamples);
+    if (dev.nranks() < 1) throw Error(ST_ECOMM, "communicator not initialised");
+    int local = ST_OK;
+    std::string local_msg;
+    try {
+      prepare();
+    } catch (const Error& e) {
+      local = e.code;
+      local_msg = e.what();
+    } catch (const std::bad_alloc&) {
+      local = ST_ENOMEM;
+      local_msg = "host allocation failed";
+    }
+    if (!begun) dev.begin_call();
+    const int agreed = dev.sharded_handshake(local);
+    if (local != ST_OK) throw Error(local, local_msg);
+    if (agreed != ST_OK)
+      throw Error(agreed, "sharded call abandoned: another rank failed before the first collective (status " + std::to_string(agreed) +
+                              "); this rank's arguments were valid");
   }
-  if (ldc < rank) throw Error(ST_EINVAL, "ldc < rank");
-  RunOpts ro = parse_opts(opts, !host_ptrs);
-  ro.sharded = sharded;
-  if (!ro.seed_explicit && !ro.omega) ro.seed = dev.fresh_seed(sharded);
-  dev.begin_call();
   const int64_t m_global = sharded ? dev.allreduce_sum_host(m) : m;  // every rank makes this call (rank-invariant)
   if (m_global < 2) throw Error(ST_EINVAL, "PCA needs at least two samples");
-  TallA<T> ta = stage_input<Dev, T>(dev, host_ptrs, x, m, n, rs, cs, sharded);
   const bool fat = !sharded && m < n;  // the tall view is x^T: its ROWS are the data columns
   // column means of x = (1/m) x^T 1: one pass of the transposed-GEMM kernel against a ones vector
   RsvdDriver<Dev, T> drv(dev, profile);
@@ -284,6 +370,8 @@ inline void pca_entry(Dev& dev, bool host_ptrs, const T* x, int64_t m, int64_t n
   dev.phase_end();
   dev.end_call();
   dev.phase_resolve(&drv.tm.total_ms);
+  drv.tm.n_collectives = dev.n_collectives;
+  drv.tm.collective_bytes = dev.collective_bytes;
   if (tm_out) *tm_out = drv.tm;
 }
 

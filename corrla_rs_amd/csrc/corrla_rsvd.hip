@@ -164,6 +164,7 @@ CORRLA_API corrla_status corrla_ctx_comm_info(corrla_ctx* ctx, int* rank, int* n
 CORRLA_API corrla_status corrla_ctx_set_phase_timings(corrla_ctx* ctx, int on) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);
+    std::lock_guard<std::mutex> lk(c->mu);  // not while a call is in flight: its marks would be left half recorded
     c->dev.set_phase_events(on != 0);
   });
 }

@@ -104,7 +104,11 @@ struct RunOpts {
   int pca_center = 0;    // 0 default, 1 fused, 2 centred copy (corrla_pca_* only)
   bool qr_householder = false;  // thin-Q by Householder TSQR instead of CholeskyQR2 (CORRLA_QR_HOUSEHOLDER)
   bool power_fused = false;     // one-sweep Z' = A^T (A Z) where it applies (CORRLA_POWER_FUSED)
+  int poison_core = 0;          // TEST HOOK (env CORRLA_TEST_POISON_CORE = 1 NaN / 2 inf): one entry of the l x l core of
+                                // random_svd.rs:89 is overwritten before its SVD; the call must end with ST_ENUMERIC
 };
+// bits of the device need_next words besides bit 0 (k::kNeedNonFinite / k::kNeedNullCols in hip_kernels.hpp)
+constexpr int kFlagNonFinite = 2, kFlagNullCols = 4;
 
 struct Timings {
   // DEVICE time of each phase: elapsed time between events recorded on the context's stream at the phase boundaries
@@ -200,6 +204,7 @@ struct RsvdDriver {
   bool robust_needs_more_ = false;         // pending_clean: a device-robust thin-Q ran out of enqueued passes
   bool svd_needs_more_ = false;            // pending_clean: the core SVD ran out of enqueued sweeps
   bool svd_needs_v_ = false;               // pending_clean: the core SVD's W-only shortcut failed its verification
+  bool null_cols_seen_ = false;            // pending_clean: some device thin-Q pass re-seeded null columns (rank-deficient sketch)
   int* flags_pool_ = nullptr;              // device words: need_next of every pass of every robust thin-Q of the call
   int flags_cap_ = 0, flags_used_ = 0;
   bool defer_status_ = false;
@@ -210,6 +215,7 @@ struct RsvdDriver {
   // rows of the WHOLE tall matrix (all ranks), fetched lazily by one scalar all-reduce the first time a rank-invariant
   // decision needs it; -1 = unknown.  Unsharded calls use the local row count.
   int64_t m_local_ = 0, m_global_ = -1;
+  int64_t m_local_override_ = -1;  // >= 0: this rank's true row count (an empty shard runs on one stand-in zero row)
   int64_t global_rows(bool sharded) {
     if (!sharded) return m_local_;
     if (m_global_ < 0) m_global_ = dev.allreduce_sum_host(m_local_);
@@ -688,7 +694,7 @@ struct RsvdDriver {
   // Leaves the orthonormal basis in `y` (mt x l) and returns its numerical rank.
   int64_t power_iter(const TallA<T>& a, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& y, Skinny<T>& y2) {
     qr_householder = o.qr_householder;
-    m_local_ = a.mt;
+    m_local_ = m_local_override_ >= 0 ? m_local_override_ : a.mt;
     PhaseTimer pt;
     Skinny<T> om = dev.template alloc_skinny<T>(a.nt, l);
     if (o.omega) {
@@ -762,7 +768,7 @@ struct RsvdDriver {
   void random_svd_tall(const TallA<T>& a, int64_t k, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& u_tall,
                        T* s_dev, Skinny<T>& v_tall, const std::function<void()>& emit = {}) {
     qr_householder = o.qr_householder;
-    m_local_ = a.mt;
+    m_local_ = m_local_override_ >= 0 ? m_local_override_ : a.mt;
     m_global_ = -1;
     hh_short_shards_ = -1;
     // Householder mode has no status records to defer: the body runs with the host in the loop, which also lets it
@@ -773,7 +779,9 @@ struct RsvdDriver {
       // (no host synchronisation inside the call).  A record that is not clean (rank deficiency, zero or
       // non-finite input, ...) repeats the computation with the host in the loop.
       const Timings saved = tm;
+      const auto mark = dev.arena_mark();  // a repeated attempt reuses the workspace of the abandoned one
       for (int attempt = 0; attempt < 5; ++attempt) {
+        if (attempt > 0) dev.arena_rewind(mark);
         // records: <= 2 per pass x <= 2 passes for each of the max(0, q - 3) in-loop, the final and the B^T thin-Q
         st_slots_ = (int)std::min<int64_t>(4 * (std::max<int64_t>(0, n_iter - 3) + 2) + 1, 4096);  // + the core SVD's
         // status records and verdict words share one zeroed allocation: ONE device-to-host copy reads both at the end
@@ -787,6 +795,7 @@ struct RsvdDriver {
         robust_needs_more_ = false;
         svd_needs_more_ = false;
         svd_needs_v_ = false;
+        null_cols_seen_ = false;
         defer_status_ = true;
         try {
           random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
@@ -811,6 +820,7 @@ struct RsvdDriver {
           break;
         }
       }
+      dev.arena_rewind(mark);
     }
     random_svd_tall_body(a, k, l, n_iter, o, u_tall, s_dev, v_tall);
     if (emit) emit();
@@ -842,6 +852,16 @@ struct RsvdDriver {
       }
       if (flags_used_ > 0) std::memcpy(flags.data(), host.data() + (size_t)st_slots_ * kStatusBytes, (size_t)flags_used_ * sizeof(int));
     }
+    // a non-finite Gram matrix or core is an error of the INPUT: nothing to escalate, nothing to repeat
+    for (int i = 0; i < flags_used_; ++i) {
+      if (flags[(size_t)i] & kFlagNonFinite) throw Error(ST_ENUMERIC, "non-finite Gram matrix in orthonormalisation");
+      if (flags[(size_t)i] & kFlagNullCols) null_cols_seen_ = true;
+    }
+    for (const Pending& p : pending_)
+      if (p.flag_slot < 0 && p.per_pass > 0)
+        for (int i = 0; i < (p.is_svd ? 1 : p.npass * p.per_pass); ++i)
+          if (fail[(size_t)p.slot + i] == 3)
+            throw Error(ST_ENUMERIC, p.is_svd ? "non-finite core matrix in small SVD" : "non-finite Gram matrix in orthonormalisation");
     for (const Pending& p : pending_) {
       if (p.flag_slot >= 0) {  // device-robust thin-Q: its last enqueued pass must not ask for another one
         // (p.slot = number of unconditional passes; conditional pass i ran iff pass i - 1 asked for it)
@@ -916,6 +936,7 @@ struct RsvdDriver {
     // C^T = Vc S Uc^T, so the roles of the two factors swap: small_svd(X) returns (V_X -> first, U_X -> second).
     Skinny<T> ct = dev.template alloc_skinny<T>(l, l);
     dev.gemm_nn(as_rowmajor_transposed(bt, l), qb, ct, kNone);
+    if (o.poison_core) dev.poison_entry(ct, l / 2, l / 3, o.poison_core);  // test hook, see RunOpts
     Skinny<T> m1 = dev.template alloc_skinny<T>(l, k);  // U~[:, :k] = Vc[:, :k]
     Skinny<T> m2 = dev.template alloc_skinny<T>(l, k);  // Uc[:, :k]
     void* svd_st = nullptr;

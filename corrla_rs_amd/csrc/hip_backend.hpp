@@ -538,6 +538,57 @@ class HipDev {
     CORRLA_HIP(hipMemcpyAsync(host, dev_p, bytes, hipMemcpyDeviceToHost, stream));
     sync();
   }
+  // TEST HOOK (CORRLA_TEST_POISON_CORE): entry (i, j) of a skinny matrix <- NaN (kind 1) / +inf (kind 2)
+  template <class T>
+  void poison_entry(Skinny<T>& s, int64_t i, int64_t j, int kind) {
+    hipLaunchKernelGGL((k::poison_entry_kernel<T>), dim3(1), dim3(1), 0, stream, s.p + j * s.ld + i, kind);
+    CORRLA_HIP(hipGetLastError());
+  }
+  // ---- workspace marks: a repeated attempt of a call (driver.hpp: random_svd_tall) reuses the workspace of the
+  // abandoned one instead of growing the arena (an ill-conditioned 10^7 x 80 call held four 3.2 GB buffers per attempt)
+  struct ArenaMark {
+    std::vector<size_t> used, zused;
+  };
+  ArenaMark arena_mark() const {
+    ArenaMark mk;
+    for (const auto& c : chunks_) mk.used.push_back(c.used);
+    for (const auto& c : zchunks_) mk.zused.push_back(c.used);
+    return mk;
+  }
+  void arena_rewind(const ArenaMark& mk) {
+    for (size_t i = 0; i < chunks_.size(); ++i) chunks_[i].used = i < mk.used.size() ? mk.used[i] : 0;
+    for (size_t i = 0; i < zchunks_.size(); ++i) {
+      Chunk& c = zchunks_[i];
+      const size_t keep = i < mk.zused.size() ? mk.zused[i] : 0;
+      // what the abandoned attempt dirtied goes back to the pool as zeros (stream order: after its kernels)
+      if (c.used > keep) CORRLA_HIP(hipMemsetAsync((char*)c.p + keep, 0, c.used - keep, stream));
+      c.zeroed = std::max(c.zeroed, c.used);
+      c.used = keep;
+    }
+  }
+  // ---- start of a sharded call: ONE small all-reduce (max) carries (a) this rank's validation / staging status, so that
+  // a rank-local failure ends the call on EVERY rank instead of leaving the peers blocked in the first collective, and
+  // (b) the adaptive schedule state of the context (thin-Q passes enqueued, extra Jacobi sweeps, sweep hint, V mode),
+  // which decides how many collectives a call enqueues and so must not differ between ranks with different histories.
+  // Returns the largest status over the ranks.  Synchronises (the stream is idle at this point of a call).
+  int sharded_handshake(int local_status) {
+    if (comm_size <= 1 && !(comm && env_int("CORRLA_FORCE_ALLREDUCE", 0))) return local_status;
+    if (!comm) throw Error(ST_ECOMM, "communicator not initialised");
+    double h[8] = {(double)local_status, (double)robust_passes_, (double)jmc_extra_sweeps_, (double)jmc_sweeps_hint_,
+                   jmc_force_v_ ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+    double* d = (double*)alloc_bytes(sizeof(h));
+    CORRLA_HIP(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, stream));
+    CORRLA_NCCL(ncclAllReduce(d, d, 8, ncclDouble, ncclMax, comm, stream));
+    ++n_collectives;
+    collective_bytes += sizeof(h);
+    CORRLA_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, stream));
+    sync();
+    robust_passes_ = (int)h[1];
+    jmc_extra_sweeps_ = (int)h[2];
+    jmc_sweeps_hint_ = (int)h[3];
+    jmc_force_v_ = h[4] != 0.0;
+    return (int)h[0];
+  }
   void read_flags(const int* dev_p, int n, int* host) {
     CORRLA_HIP(hipMemcpyAsync(host, dev_p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, stream));
     sync();
@@ -595,6 +646,7 @@ class HipDev {
 
   void read_chol_status(const void* st_dev, int n, int* fail, float* min_ratio, float* dev_i) {
     static_assert(sizeof(k::CholStatus) == 32, "driver.hpp assumes 32-byte status records");
+    static_assert(k::kNeedNonFinite == kFlagNonFinite && k::kNeedNullCols == kFlagNullCols, "need_next bits: kernels vs driver");
     std::vector<k::CholStatus> h((size_t)std::max(n, 1));
     CORRLA_HIP(hipMemcpyAsync(h.data(), st_dev, sizeof(k::CholStatus) * n, hipMemcpyDeviceToHost, stream));
     sync();
@@ -884,6 +936,7 @@ class HipDev {
       done = s1;
       if (conv || h.bad) break;
     }
+    if (h.bad) throw Error(ST_ENUMERIC, "non-finite core matrix in small SVD");
     finish(done);
     if (env_int("CORRLA_DEBUG", 0)) {
       int used = 0;
@@ -931,6 +984,20 @@ class HipDev {
     if (want_host || l > 1024) {
       small_svd_host(*this, c, l, k, m1, m2, s_dev);
       return;
+    }
+    // The single-workgroup and block Jacobi kernels carry no status word: a non-finite core would come back as a
+    // triplet of zeros.  One small launch scans the core first: optimistic runs find fail = 3 in the status record at
+    // the end of the call, host-controlled ones read the word now.
+    {
+      int* bad = conv_status ? nullptr : alloc_flags(1);
+      hipLaunchKernelGGL((k::core_finite_check_kernel<T>), dim3(1), dim3(1024), 0, stream, (const T*)c.p, c.ld, (int)l,
+                         (k::CholStatus*)conv_status, bad);
+      CORRLA_HIP(hipGetLastError());
+      if (bad) {
+        int h = 0;
+        read_flags(bad, 1, &h);
+        if (h) throw Error(ST_ENUMERIC, "non-finite core matrix in small SVD");
+      }
     }
     const bool want_block = mode && std::strcmp(mode, "block") == 0;
     (void)want_lds;

@@ -2226,6 +2226,9 @@ struct CholStatus {
 //    null columns, or its Gram was further than 0.25 from I), else 0: the kernels of the next pass carry it as their
 //    run_if word;
 //  * run_if: the whole launch does nothing when *run_if == 0.
+// bits of a need_next word besides bit 0 ("run another pass"): what the pass saw, for the host's end-of-call verdict
+constexpr int kNeedNonFinite = 2;  // a non-finite Gram matrix: the call ends with CORRLA_ENUMERIC, nothing to escalate
+constexpr int kNeedNullCols = 4;   // null columns were found (and re-seeded at random): the sketch is rank deficient
 struct CholRobust {
   float shift_rel;
   int shift_mode;  // 0: shift iff ||G - I||_max > 0.25, 1: always, 2: never
@@ -2301,7 +2304,12 @@ template <class T>
 __global__ void combine_need_kernel(int* need, const GramInspect<T>* insp, const int* na, const int* nb, const int* run_if) {
   if (run_if && *run_if == 0) return;
   // insp == nullptr (the single pass of an in-loop thin-Q): the verdict is that of the two block factorisations alone
-  *need = ((insp && (insp->shifted || insp->bad || insp->d2 > 0.05f)) || *na || *nb) ? 1 : 0;
+  // bit 0: another pass is needed; bit 1 (kNeedNonFinite): a non-finite Gram; bit 2 (kNeedNullCols): null columns were
+  // re-seeded -- the host reads the words once at the end of the call (driver.hpp: pending_clean)
+  const int sub = *na | *nb;
+  const int bad = (insp && insp->bad) ? kNeedNonFinite : 0;
+  const int need1 = ((insp && (insp->shifted || insp->bad || insp->d2 > 0.05f)) || sub) ? 1 : 0;
+  *need = need1 | bad | (sub & (kNeedNonFinite | kNeedNullCols));
 }
 // threads: one per 4 x 4 tile of the upper triangle.  f64 keeps 2 x 16 doubles of tile data per thread: at 1024 threads
 // (128 VGPRs) the compiler spilled 22 of them into the elimination loop (287 us at r = 138 against 62 us in f32), so
@@ -2396,7 +2404,7 @@ __global__ __launch_bounds__(chol_inv_max_threads<T>()) void chol_inv_kernel(con
         }
     }
     if (tid == 0) {
-      *rq.need_next = 1;
+      *rq.need_next = 1 | kNeedNullCols;
       st->fail = 0;
       st->min_ratio = 0.f;
       st->dev_i = d2;
@@ -2542,10 +2550,12 @@ __global__ __launch_bounds__(chol_inv_max_threads<T>()) void chol_inv_kernel(con
   if (tid == 0) {
     // a plain pass on a Gram within 0.05 of I leaves the product orthonormal to a few eps * sqrt(m)
     if (robust) {
+      int need;
       if (rq.need_ratio > 0.f)
-        *rq.need_next = (nnull > 0 || min_ratio < rq.need_ratio || fl != 0) ? 1 : 0;
+        need = (nnull > 0 || min_ratio < rq.need_ratio || fl != 0) ? 1 : 0;
       else
-        *rq.need_next = (nnull > 0 || d2 > 0.05f || (shifted && !rq.abs_shift) || fl != 0) ? 1 : 0;
+        need = (nnull > 0 || d2 > 0.05f || (shifted && !rq.abs_shift) || fl != 0) ? 1 : 0;
+      *rq.need_next = need | (fl == 3 ? kNeedNonFinite : 0) | (nnull > 0 ? kNeedNullCols : 0);
     }
     st->fail = fl;
     st->min_ratio = nnull > 0 ? 0.f : min_ratio;
@@ -2592,6 +2602,30 @@ __global__ void series_combine_kernel(const T* e1, const T* e2, const T* e3, int
   if (i >= r || j >= r) return;
   const int64_t o = (int64_t)j * ld + i;
   m[(int64_t)j * ldm + i] = (i == j ? (T)1 : (T)0) - (T)0.5 * e1[o] + (T)0.375 * e2[o] - (T)0.3125 * e3[o];
+}
+
+// ---- non-finite cores -------------------------------------------------------------------------------
+// One workgroup scans the l x l core of the small SVD (random_svd.rs:89) before a kernel family that has no status
+// word of its own (ring / LDS / split / block Jacobi): *bad <- 1 and, when a status record is given, st->fail <- 3,
+// so that a non-finite core ends the call with CORRLA_ENUMERIC instead of a triplet of zeros.  (The multi-workgroup
+// Jacobi reports the same through jmc_init_kernel / jmc_finish_kernel.)
+template <class T>
+__global__ __launch_bounds__(1024) void core_finite_check_kernel(const T* __restrict__ c, int64_t ld, int l, CholStatus* st, int* bad_out) {
+  int bad = 0;
+  for (int idx = threadIdx.x; idx < l * l; idx += 1024) {
+    const int j = idx / l, i = idx - j * l;
+    if (!((float)fabs(c[(int64_t)j * ld + i]) < 3.0e38f)) bad = 1;
+  }
+  bad = __syncthreads_or(bad);
+  if (threadIdx.x == 0 && bad) {
+    if (st) st->fail = 3;
+    if (bad_out) *bad_out = 1;
+  }
+}
+// TEST HOOK (CORRLA_TEST_POISON_CORE, tests/test_gpu_parity.py): one entry of a device matrix <- NaN (kind 1) / +inf (2)
+template <class T>
+__global__ void poison_entry_kernel(T* p, int kind) {
+  *p = kind == 2 ? std::numeric_limits<T>::infinity() : std::numeric_limits<T>::quiet_NaN();
 }
 
 // ---- PCA caller: centring (center_mat_col, mat_utils.rs:482-502) -----------------------------------

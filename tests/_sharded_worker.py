@@ -20,11 +20,12 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     calls = {"n": 0, "bytes": 0}
 
-    def allreduce(buf, count, is_f64):
+    def allreduce(buf, count, flags):
+        is_f64, is_max = bool(flags & 1), bool(flags & 2)   # bit 1: MAX (the handshake at the start of a sharded call)
         dt = np.float64 if is_f64 else np.float32
         arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double if is_f64 else C.c_float)), shape=(count,))
         t = torch.from_numpy(arr)
-        dist.all_reduce(t)  # in place (shares memory with the C buffer)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if is_max else dist.ReduceOp.SUM)  # in place (shares memory with the C buffer)
         calls["n"] += 1
         calls["bytes"] += count * np.dtype(dt).itemsize
 
@@ -33,6 +34,8 @@ def main():
     emu().corrla_emu_set_rank(rank)
 
     d = np.load(os.path.join(out_dir, "input.npz"))
+    if "escalate_rank" in d.files and int(d["escalate_rank"]) == rank:
+        os.environ["CORRLA_ROBUST_PASSES"] = "8"   # this rank's context starts escalated (read when the backend is created)
     a, omega = d["A"], d["omega"]
     k, q, p = int(d["k"]), int(d["q"]), int(d["p"])
     m = a.shape[0]
@@ -53,6 +56,23 @@ def main():
         return
     shard_cols = "shard_cols" in d.files and int(d["shard_cols"]) == 1
     qr = "householder" if "householder" in d.files and int(d["householder"]) == 1 else None
+    # fail_rank: that rank passes ldu = m_local - 1 (a rank-LOCAL argument error); every rank must come back with an
+    # error instead of blocking in its first collective
+    fail_rank = int(d["fail_rank"]) if "fail_rank" in d.files else -1
+    if fail_rank >= 0:
+        a_loc = np.ascontiguousarray(a[lo:hi].astype(np.float64))
+        try:
+            emu_rsvd(a_loc, k, q, p, omega=omega, sharded=True, bad_ldu=(rank == fail_rank))
+            outcome = "ok"
+        except ValueError as e:
+            outcome = "ValueError: " + str(e)
+        except RuntimeError as e:
+            outcome = "RuntimeError: " + str(e)
+        with open(os.path.join(out_dir, f"outcome_rank{rank}.txt"), "w") as f:
+            f.write(outcome)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for dtype in (np.float64, np.float32):
         if shard_cols:     # fat matrix, this rank's COLUMNS (lo/hi index the columns)
             n = a.shape[1]

@@ -176,6 +176,24 @@ class EmuDev {
     collective_bytes += (double)count * sizeof(T);
   }
   void allreduce_f64(double* p, size_t count) { allreduce<double>(p, count); }
+  // HipDev::sharded_handshake: one MAX all-reduce of (status, schedule state) at the start of a sharded call
+  // (callback flag bit 1 = max instead of sum)
+  int sharded_handshake(int local_status) {
+    if (g_nranks <= 1) return local_status;
+    if (!g_allreduce) throw Error(ST_ECOMM, "emu: no allreduce callback");
+    double h[8] = {(double)local_status, (double)robust_passes_, 0, 0, 0, 0, 0, 0};
+    g_allreduce(h, 8, 1 | 2);
+    ++n_collectives;
+    collective_bytes += sizeof(h);
+    robust_passes_ = (int)h[1];
+    return (int)h[0];
+  }
+  int arena_mark() const { return 0; }
+  void arena_rewind(int) {}
+  template <class T>
+  void poison_entry(Skinny<T>& s, int64_t i, int64_t j, int kind) {
+    s.p[j * s.ld + i] = kind == 2 ? std::numeric_limits<T>::infinity() : std::numeric_limits<T>::quiet_NaN();
+  }
   int64_t allreduce_sum_host(int64_t v) {
     if (g_nranks <= 1) return v;
     double h = (double)v;
@@ -524,7 +542,9 @@ class EmuDev {
   void combine_need(int* need, const void* insp, const int* na, const int* nb) {
     if (skipped()) return;
     const EmuInspect<T>* o = (const EmuInspect<T>*)insp;
-    *need = ((o && (o->shifted || o->bad || o->d2 > 0.05f)) || *na || *nb) ? 1 : 0;
+    const int sub = *na | *nb;
+    *need = (((o && (o->shifted || o->bad || o->d2 > 0.05f)) || sub) ? 1 : 0) | ((o && o->bad) ? kFlagNonFinite : 0) |
+            (sub & (kFlagNonFinite | kFlagNullCols));
   }
   // k::chol_inv_kernel with a CholRobust record: shifted factorisation, failed pivots are null columns (zero columns of
   // R^-1, the factor is that of the Gram with those rows and columns deleted), need_next / null_mask outputs
@@ -552,12 +572,12 @@ class EmuDev {
     st->fail = 0;
     if (!finite) {
       st->fail = 3;
-      *need_next = 1;
+      *need_next = 1 | kFlagNonFinite;
       return;
     }
     if (!(gm > 0.0)) {  // the zero matrix: every column is null
       for (int64_t j = 0; j < r; ++j) null_mask[j] = 1;
-      *need_next = 1;
+      *need_next = 1 | kFlagNullCols;
       return;
     }
     if (dv <= (sizeof(T) == 4 ? 2.0e-4 : 1.0e-8)) {
@@ -620,6 +640,7 @@ class EmuDev {
       *need_next = (nnull > 0 || mr < (double)need_ratio) ? 1 : 0;
     else
       *need_next = (nnull > 0 || dv > 0.05 || (shifted && !abs_shift)) ? 1 : 0;
+    if (nnull > 0) *need_next |= kFlagNullCols;
   }
   template <class T>
   void apply_inplace(Skinny<T>& y, int64_t l, const Skinny<T>& m) {

@@ -40,13 +40,16 @@ def _opts(omega, nt, l, dtype, seed=None, flags=0):
     return o, keep
 
 
-def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=False, qr=None, fused=False, shard_cols=False):
+def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=False, qr=None, fused=False, shard_cols=False,
+             bad_ldu=False):
     e = emu()
     a = np.asarray(a)
     dtype = a.dtype
     suf = "f32" if dtype == np.float32 else "f64"
     m, n = a.shape
     rs, cs = a.strides[0] // a.itemsize, a.strides[1] // a.itemsize
+    if a.size == 0:      # an empty shard of a sharded call: strides are immaterial
+        rs, cs = max(n, 1), 1
     nt = (m if shard_cols else n) if sharded else min(m, n)
     l = min(k + p, nt)
     o, keep = _opts(omega, nt, l, dtype, seed, (L.QR_HOUSEHOLDER if qr == "householder" else 0) | (L.POWER_FUSED if fused else 0) |
@@ -57,7 +60,7 @@ def emu_rsvd(a, k, q, p, omega=None, seed=None, sharded=False, return_passes=Fal
     i64 = C.c_int64
     passes = C.c_int(0)
     args = [C.c_void_p(a.ctypes.data), i64(m), i64(n), i64(rs), i64(cs), i64(k), i64(q), i64(p),
-            C.byref(o) if o is not None else None, C.c_void_p(u.ctypes.data), i64(m), C.c_void_p(s.ctypes.data),
+            C.byref(o) if o is not None else None, C.c_void_p(u.ctypes.data), i64(m - 1 if bad_ldu else m), C.c_void_p(s.ctypes.data),
             C.c_void_p(vt.ctypes.data), i64(max(k, 1))]
     if sharded:
         rc = getattr(e, "corrla_emu_rsvd_sharded_" + suf)(*args)

@@ -40,3 +40,39 @@ def test_self_launch_spawns_n_ranks_and_relays_rank0(monkeypatch):
     env["CORRLA_BENCH_DRYRUN_RC"] = "3"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, timeout=120)
     assert r.returncode == 3
+
+
+def test_a_dead_rank_ends_the_whole_launch_quickly():
+    """Rank 1 exits with an error at once while rank 0 'hangs' (sleeps 120 s, standing for a rank blocked in an RCCL
+    collective): the parent must notice the failure, end rank 0 and return rank 1's code within seconds -- not wait for
+    rank 0 first (bench.py used to wait on the ranks in order, up to 50 minutes with the GPUs held)."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(CORRLA_BENCH_DRYRUN="1", CORRLA_BENCH_DRYRUN_RC="3", CORRLA_BENCH_DRYRUN_SLEEP_RANK0="120")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, timeout=100)
+    assert r.returncode == 3 and time.time() - t0 < 60
+
+
+def test_sigterm_to_the_launcher_takes_the_ranks_down():
+    """`timeout` (or the driver) signals the parent: no rank process may survive it."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(CORRLA_BENCH_DRYRUN="1", CORRLA_BENCH_DRYRUN_SLEEP_RANK0="120", CORRLA_BENCH_TAG="sigterm-test-%d" % os.getpid())
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE)
+    time.sleep(3.0)      # the ranks are up (rank 0 asleep)
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    tag = env["CORRLA_BENCH_TAG"].encode()
+    left = []
+    for pid in os.listdir("/proc"):
+        if pid.isdigit():
+            try:
+                if tag in open(f"/proc/{pid}/environ", "rb").read():
+                    left.append(pid)
+            except OSError:
+                pass
+    assert not left, f"rank processes survived the launcher: {left}"

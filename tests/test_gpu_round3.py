@@ -1,0 +1,140 @@
+"""GPU parity tests added in round 3 (run with -m gpu on an MI355X): non-finite cores through every core-SVD kernel
+family, sketches wider than the device Cholesky serves (l > 352), the rank-deficient f32 cases the fuzz sweep of
+round 2 left outside its bound, empty shards and the sharded handshake on a one-rank RCCL communicator."""
+import numpy as np
+import pytest
+
+from oracle import rsvd_oracle as orc
+from tests.helpers import check_factorization, orth_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import corrla_rs_amd as cr
+    return cr.Context(0)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+# ---- a non-finite l x l core must end the call with CORRLA_ENUMERIC, whatever kernel family takes its SVD ------------
+# (round 2: a non-finite core made the final ranking of the Jacobi kernels keep uninitialised column indices -> a wild
+#  read and an abort; fixed in the kernels, pinned here.  CORRLA_TEST_POISON_CORE overwrites entry (l/2, l/3) of the core
+#  formed at random_svd.rs:89 with NaN (1) / +inf (2), AFTER both thin-Qs, so nothing upstream can catch it.)
+_POISON_CASES = [
+    # (l, environment that selects the kernel family)
+    (24, {}),                                            # ring (W only) + replay, one wave
+    (75, {}),                                            # ring (W only) + replay, odd pair count
+    (75, {"CORRLA_JACOBI_NOREPLAY": "1"}),               # ring with V accumulated in the kernel
+    (75, {"CORRLA_JACOBI_NORING": "1"}),                 # role-split LDS kernel
+    (75, {"CORRLA_JACOBI_NORING": "1", "CORRLA_JACOBI_NOSPLIT": "1"}),  # LDS-resident kernel
+    (96, {}),                                            # multi-workgroup block Jacobi, smallest
+    (138, {}),                                           # ... the C2 width
+    (138, {"CORRLA_JMC_FORCE_V": "1"}),                  # ... with V accumulated in the sweeps
+    (266, {}),                                           # ... the C3 width (2 x 2 blocked Cholesky around it)
+    (138, {"CORRLA_SVD": "lds"}),                        # ring kernel at a width the default gives to the block Jacobi
+    (138, {"CORRLA_SVD": "lds", "CORRLA_JACOBI_NORING": "1"}),   # split kernel, widest
+    (170, {"CORRLA_SVD": "lds"}),                        # LDS-resident kernel beyond the ring / split widths
+    (138, {"CORRLA_SVD": "block"}),                      # one launch per round (MFMA block kernel)
+    (300, {}),                                           # beyond the multi-workgroup geometry: block kernel
+    (138, {"CORRLA_SVD": "host"}),                       # host Jacobi
+    (138, {"CORRLA_DEVICE_ROBUST_QR": "0"}),             # round-1 optimistic CholeskyQR2 records around the same core
+    (138, {"CORRLA_HOST_CHOL": "1"}),                    # host-controlled thin-Q (no deferred status at all)
+]
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("case", range(len(_POISON_CASES)))
+def test_non_finite_core_is_an_error_in_every_svd_kernel_family(ctx, monkeypatch, case, dtype, kind):
+    from corrla_rs_amd._lib import CorrlaError
+    l, env = _POISON_CASES[case]
+    rng = np.random.default_rng(100 + case)
+    m, n = max(3 * l, 200), l + 25
+    a = rng.standard_normal((m, n)).astype(dtype)
+    k, p = l - 8, 8
+    om = rng.standard_normal((n, l)).astype(dtype)
+    for name, val in env.items():
+        monkeypatch.setenv(name, val)
+    monkeypatch.setenv("CORRLA_TEST_POISON_CORE", str(kind))
+    with pytest.raises(CorrlaError) as e:
+        ctx.rsvd(a, k, 2, p, omega=om)
+    assert e.value.code == 5, str(e.value)  # CORRLA_ENUMERIC
+    # ... and the context is as good as new afterwards: same call without the poison, against the oracle
+    monkeypatch.delenv("CORRLA_TEST_POISON_CORE")
+    u, s, vt = ctx.rsvd(a, k, 2, p, omega=om)
+    uo, so, vto = orc.random_svd(a, k, 2, p, omega=om)
+    assert np.all(np.isfinite(u)) and np.all(np.isfinite(s)) and np.all(np.isfinite(vt))
+    assert np.max(np.abs(s.ravel().astype(np.float64) - so.ravel())) <= (3e-5 if dtype == np.float32 else 1e-10) * so[0, 0]
+
+
+# ---- sketches wider than the device Cholesky serves (l > 352): the host-controlled thin-Q, block / host core SVD ------
+# random_svd.rs:76-77 puts no limit on l = min(rank + p, n); rank 512 of a few-thousand-column matrix is an ordinary call
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m,n,k,p", [(1400, 640, 390, 10),      # l = 400
+                                     (2048, 800, 502, 10),      # l = 512
+                                     (2600, 1300, 1024, 10)])   # l = 1034: beyond the block Jacobi (host SVD)
+def test_sketches_wider_than_352_columns(ctx, m, n, k, p, dtype):
+    rng = np.random.default_rng(m + k)
+    a = (rng.standard_normal((m, n)) * (0.999 ** np.arange(n))).astype(dtype)
+    l = min(k + p, n)
+    om = rng.standard_normal((n, l)).astype(dtype)
+    u, s, vt = ctx.rsvd(a, k, 2, p, omega=om)
+    uo, so, vto = orc.random_svd(a, k, 2, p, omega=om)
+    check_factorization(a, u, s, vt, k, 0)
+    f64 = dtype == np.float64
+    s1 = float(so[0, 0])
+    assert np.max(np.abs(s.ravel().astype(np.float64) - so.ravel())) <= (1e-10 if f64 else 2e-5) * s1
+    assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-5      # the north star's gate
+    rec = (u.astype(np.float64) * s.ravel()) @ vt.astype(np.float64)
+    reco = (uo.astype(np.float64) * so.ravel()) @ vto.astype(np.float64)
+    assert np.linalg.norm(rec - reco) <= (1e-8 if f64 else 1e-3) * np.linalg.norm(reco)
+    eps = np.finfo(dtype).eps
+    assert orth_err(u) <= 200 * eps * np.sqrt(m) and orth_err(vt.T) <= 200 * eps * np.sqrt(n)
+
+
+def test_wide_sketch_device_tensor_and_fat_orientation(ctx, torch):
+    """l = 420 through the device-pointer entry, fat input (the tall view is A^T, random_svd.rs:69-74)."""
+    rng = np.random.default_rng(77)
+    m, n, k, p = 520, 1500, 410, 10
+    a = rng.standard_normal((m, n))
+    om = rng.standard_normal((m, k + p))
+    u, s, vt = ctx.rsvd(torch.tensor(a, device="cuda"), k, 1, p, omega=om)
+    u, s, vt = u.cpu().numpy(), s.cpu().numpy(), vt.cpu().numpy()
+    uo, so, vto = orc.random_svd(a, k, 1, p, omega=om)
+    assert np.max(np.abs(s - so)) <= 1e-10 * so[0, 0]
+    assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-9
+
+
+# ---- empty shards and the handshake on a one-rank RCCL communicator ---------------------------------------------------
+def test_sharded_handshake_and_empty_shard_world_size_1(torch, monkeypatch):
+    """World size 1 with every collective issued to RCCL (CORRLA_FORCE_ALLREDUCE): the MAX all-reduce of the handshake
+    at the start of a sharded call is a real ncclAllReduce; a rank-local argument error still comes back as this rank's
+    own error; a call on an empty block is refused on a one-rank communicator only because the GLOBAL matrix is then
+    empty (rank > rows), not by a crash."""
+    import corrla_rs_amd as cr
+    c = cr.Context(0)
+    c.comm_init(cr.Context.unique_id(), 0, 1)
+    monkeypatch.setenv("CORRLA_FORCE_ALLREDUCE", "1")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn((2000, 96), dtype=torch.float64, device="cuda", generator=g)
+    om = np.random.default_rng(5).standard_normal((96, 20))
+    u1, s1, vt1 = c.rsvd_sharded(a, 12, 2, 8, omega=om)
+    n_coll = c.timings()["n_collectives"]
+    assert n_coll == 1 + 3 + 2          # handshake + (q + 1) n x l all-reduces + two Gram all-reduces of the final thin-Q
+    u0, s0, vt0 = c.rsvd(a, 12, 2, 8, omega=om)
+    assert torch.equal(s0, s1) and torch.equal(u0, u1) and torch.equal(vt0, vt1)
+    with pytest.raises(ValueError):
+        c.rsvd_sharded(a, 200, 2, 8)        # rank > n: the local error, not 'another rank failed'
+    # an empty block on the only rank: the stand-in zero row keeps every kernel launch well formed; the matrix has rank 0,
+    # so S = 0 and the call completes (orthonormal completion), no fault
+    e = torch.empty((0, 96), dtype=torch.float64, device="cuda")
+    ue, se, vte = c.rsvd_sharded(e, 12, 2, 8, omega=om)
+    assert ue.shape == (0, 12) and float(se.abs().max()) == 0.0 and bool(torch.isfinite(vte).all())
+    c.close()

@@ -46,8 +46,9 @@ def test_row_sharded_world2_matches_single_rank():
             # all-reduce per in-loop orthonormalisation (i > 2, single pass) and two for the final thin-Q (well-conditioned
             # input: the context never had to enqueue conditional passes, whose Gram all-reduces would be unconditional).
             # No scalar all-reduce: the per-iteration rescale uses ||Z||_F, and Z is already replicated.
+            # + 1: the handshake at the start of every sharded call (status + schedule state, one MAX all-reduce of 8 words)
             n_ar = int(outs[0]["n_allreduce"])
-            assert n_ar == (q + 1) + max(0, q - 3) + 2
+            assert n_ar == 1 + (q + 1) + max(0, q - 3) + 2
 
 
 @pytest.mark.timeout(300)
@@ -195,3 +196,84 @@ def test_row_sharded_householder_tsqr_world2(case):
             assert np.linalg.norm(rec - rec1) <= 100 * tol * np.linalg.norm(rec1)
             uo, so, vto = orc.random_svd(a.astype(dtype), k, q, p, omega=omega.astype(dtype))
             assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-5
+
+
+def _run_world(td, world, port, extra_env=None, per_rank_env=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "_sharded_worker.py"), td]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+
+
+@pytest.mark.timeout(300)
+def test_row_sharded_world4_with_an_empty_shard():
+    """More ranks than row blocks: rank 1 holds NO rows (m_local = 0).  It takes part in every collective with zero
+    contributions and returns a 0 x k block of U; the other three ranks' blocks stack to the single-rank result."""
+    rng = np.random.default_rng(17)
+    m, n, k, q, p = 180, 48, 9, 4, 7
+    a = rng.standard_normal((m, n)) * (0.97 ** np.arange(n))
+    omega = rng.standard_normal((n, k + p))
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "input.npz"), A=a, omega=omega, k=k, q=q, p=p, splits=np.array([0, 50, 50, 121, 180]))
+        r = _run_world(td, 4, "29561")
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        for dtype, tol in ((np.float64, 1e-10), (np.float32, 5e-5)):
+            name = np.dtype(dtype).name
+            outs = [np.load(os.path.join(td, f"out_{name}_rank{r_}.npz")) for r_ in range(4)]
+            assert outs[1]["u"].shape == (0, k)
+            for o in outs[1:]:
+                assert np.array_equal(outs[0]["s"], o["s"]) and np.array_equal(outs[0]["vt"], o["vt"])
+            assert len({int(o["n_allreduce"]) for o in outs}) == 1          # every rank issued the same collectives
+            u = np.vstack([o["u"] for o in outs])
+            s, vt = outs[0]["s"], outs[0]["vt"]
+            u1, s1, vt1 = emu_rsvd(a.astype(dtype), k, q, p, omega=omega.astype(dtype))
+            assert np.max(np.abs(s - s1)) <= tol * s1[0, 0]
+            rec = (u.astype(np.float64) * s.ravel()) @ vt
+            rec1 = (u1.astype(np.float64) * s1.ravel()) @ vt1
+            assert np.linalg.norm(rec - rec1) <= 100 * tol * np.linalg.norm(rec1)
+            uo, so, vto = orc.random_svd(a.astype(dtype), k, q, p, omega=omega.astype(dtype))
+            assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= 1e-5
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_local_failure_ends_the_call_on_every_rank_world4():
+    """Rank 2 passes a bad leading dimension (ldu < m_local): without the handshake its three peers would sit in the
+    first all-reduce for ever.  Every rank must return an error: the failing one its own, the others 'another rank
+    failed'."""
+    rng = np.random.default_rng(18)
+    m, n, k, q, p = 120, 32, 6, 2, 6
+    a = rng.standard_normal((m, n))
+    omega = rng.standard_normal((n, k + p))
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "input.npz"), A=a, omega=omega, k=k, q=q, p=p, fail_rank=2)
+        r = _run_world(td, 4, "29563")
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        outcomes = [open(os.path.join(td, f"outcome_rank{r_}.txt")).read() for r_ in range(4)]
+        assert outcomes[2].startswith("ValueError") and "ldu < m" in outcomes[2], outcomes
+        for r_ in (0, 1, 3):
+            assert outcomes[r_].startswith("ValueError") and "another rank failed" in outcomes[r_], outcomes
+
+
+@pytest.mark.timeout(300)
+def test_ranks_with_different_context_histories_enqueue_the_same_collectives():
+    """The number of thin-Q passes a call enqueues (each with a Gram all-reduce) is adaptive context state.  Rank 0
+    starts at 8 passes (CORRLA_ROBUST_PASSES, standing for a context that an earlier ill-conditioned call escalated),
+    rank 1 at the default 2: the handshake at the start of the call levels the state, so both ranks issue the same
+    sequence of collectives (mismatched sequences hang or mis-pair buffers)."""
+    rng = np.random.default_rng(19)
+    m, n, k, q, p = 160, 40, 8, 5, 6
+    a = rng.standard_normal((m, n)) * (0.9 ** np.arange(n))
+    omega = rng.standard_normal((n, k + p))
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "input.npz"), A=a, omega=omega, k=k, q=q, p=p, escalate_rank=0)
+        r = _run_world(td, 2, "29565")
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        for dtype, tol in ((np.float64, 1e-9), (np.float32, 2e-4)):
+            name = np.dtype(dtype).name
+            outs = [np.load(os.path.join(td, f"out_{name}_rank{r_}.npz")) for r_ in range(2)]
+            assert int(outs[0]["n_allreduce"]) == int(outs[1]["n_allreduce"])
+            assert np.array_equal(outs[0]["s"], outs[1]["s"]) and np.array_equal(outs[0]["vt"], outs[1]["vt"])
+            u = np.vstack([o["u"] for o in outs])
+            uo, so, vto = orc.random_svd(a.astype(dtype), k, q, p, omega=omega.astype(dtype))
+            assert abs(orc.relerr(a, u, outs[0]["s"], outs[0]["vt"]) - orc.relerr(a, uo, so, vto)) <= 1e-5

@@ -11,12 +11,10 @@ from oracle import rsvd_oracle as orc  # noqa: E402
 
 
 
-def run(n_cases=200, seed=0, ctx=None, verbose=True, wide=False):
-  """Returns (violations, worst f64 deviations)."""
+def cases(n_cases, seed, wide=False):
+  """The case stream of the sweep (one generator state per seed): yields (case index, a, omega, k, q, p, l, kind, dtype,
+  householder) for every case the sweep compares; tools/fuzz_replay.py and tests/test_gpu_round3.py replay single cases."""
   rng = np.random.default_rng(seed)
-  ctx = ctx or cr.Context(0)
-  worst = {"ds": 0.0, "relerr": 0.0, "orth": 0.0}
-  bad = 0
   for case in range(n_cases):
       # wide: sketches of up to 352 columns (two column blocks, 2 x 2 blocked factorisations)
       m = int(rng.integers(1, 1500 if wide else 700))
@@ -50,9 +48,20 @@ def run(n_cases=200, seed=0, ctx=None, verbose=True, wide=False):
           pass
       elif (sv[l - 1] / sv[0]) ** (2 * min(q, 3) + 1) < 1e4 * eps:
           continue
+      # a third of the cases through the Householder TSQR thin-Q (wider sketches fall back to the default inside)
+      hh = rng.random() < 0.33
+      yield case, a, om, k, q, p, l, str(kind), dtype, hh
+
+
+def run(n_cases=200, seed=0, ctx=None, verbose=True, wide=False):
+  """Returns (violations, worst f64 deviations)."""
+  ctx = ctx or cr.Context(0)
+  worst = {"ds": 0.0, "relerr": 0.0, "orth": 0.0}
+  bad = 0
+  for case, a, om, k, q, p, l, kind, dtype, hh in cases(n_cases, seed, wide):
+      m, n = a.shape
       try:
-          # a third of the cases through the Householder TSQR thin-Q (wider sketches fall back to the default inside)
-          u, s, vt = ctx.rsvd(a, k, q, p, omega=om, qr="householder" if rng.random() < 0.33 else None)
+          u, s, vt = ctx.rsvd(a, k, q, p, omega=om, qr="householder" if hh else None)
       except Exception as e:  # noqa: BLE001
           if verbose: print("EXCEPTION", case, (m, n), dtype.__name__, kind, k, q, p, repr(e)[:200])
           bad += 1
