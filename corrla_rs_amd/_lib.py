@@ -18,6 +18,8 @@ QR_HOUSEHOLDER = 0x8
 SEED_EXPLICIT = 0x10
 POWER_FUSED = 0x20
 SHARD_COLS = 0x40
+SKETCH_BF16X3 = 0x80
+SKETCH_BF16X6 = 0x100
 UNIQUE_ID_BYTES = 128
 
 
@@ -28,7 +30,8 @@ class Opts(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("total_ms", dbl), ("sketch_ms", dbl), ("power_ms", dbl), ("qr_ms", dbl), ("project_ms", dbl),
                 ("small_svd_ms", dbl), ("finalize_ms", dbl), ("qr_passes", i32), ("n_collectives", i32),
-                ("sketch_kernel_ms", dbl), ("host_enqueue_ms", dbl), ("collective_bytes", dbl)]
+                ("sketch_kernel_ms", dbl), ("host_enqueue_ms", dbl), ("collective_bytes", dbl), ("n_mixed_products", i32),
+                ("reserved_", i32)]
 
 
 # symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header

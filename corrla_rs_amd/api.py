@@ -108,6 +108,19 @@ class Context:
             return L.QR_HOUSEHOLDER
         raise ValueError("qr must be None, 'cholesky' or 'householder'")
 
+    @staticmethod
+    def _mixed_flag(mixed):
+        """mixed=None: exact f32 / f64 products (default).  "bf16x6" / "bf16x3": the tall products of the range finder
+        (random_svd.rs:31, 42-51) on the bf16 matrix units with f32 accumulation, every f32 operand split on the fly into
+        three / two bf16 pieces (CORRLA_SKETCH_BF16X6 / X3; f32 row-major inputs with l <= 144, ignored elsewhere)."""
+        if mixed in (None, False, "f32"):
+            return 0
+        if mixed == "bf16x6":
+            return L.SKETCH_BF16X6
+        if mixed == "bf16x3":
+            return L.SKETCH_BF16X3
+        raise ValueError("mixed must be None, 'bf16x3' or 'bf16x6'")
+
     def _opts(self, seed, omega, nt, l, dtype, on_device, extra_flags=0):
         if seed is None and omega is None and not extra_flags:
             return None, None
@@ -136,11 +149,12 @@ class Context:
         return o, keep
 
     # ---- random_svd ----------------------------------------------------------------------
-    def rsvd(self, a_mat, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, qr=None, fused=False):
-        """fused=True: CORRLA_POWER_FUSED (one-sweep A^T (A Z) power iteration; f32 row-major inputs with <= 512 columns)."""
+    def rsvd(self, a_mat, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, qr=None, fused=False, mixed=None):
+        """fused=True: CORRLA_POWER_FUSED (one-sweep A^T (A Z) power iteration; f32 row-major inputs with <= 512 columns).
+        mixed="bf16x6" | "bf16x3": see _mixed_flag."""
         n_rank, n_iters, n_oversamples = int(n_rank), int(n_iters), int(n_oversamples)
         if _is_torch(a_mat) and a_mat.is_cuda:
-            return self._rsvd_torch(a_mat, n_rank, n_iters, n_oversamples, seed, omega, qr=qr, fused=fused)
+            return self._rsvd_torch(a_mat, n_rank, n_iters, n_oversamples, seed, omega, qr=qr, fused=fused, mixed=mixed)
         a = np.asarray(a_mat.detach().cpu().numpy() if _is_torch(a_mat) else a_mat)
         if a.ndim != 2:
             raise ValueError("a_mat must be 2-D")
@@ -156,7 +170,7 @@ class Context:
         k = n_rank
         nt = min(m, n)
         l = min(k + max(n_oversamples, 0), nt)
-        o, keep = self._opts(seed, omega, nt, l, a.dtype, False, self._qr_flag(qr) | (L.POWER_FUSED if fused else 0))
+        o, keep = self._opts(seed, omega, nt, l, a.dtype, False, self._qr_flag(qr) | (L.POWER_FUSED if fused else 0) | self._mixed_flag(mixed))
         kk = max(k, 1)
         u = np.empty((m, kk), dtype=a.dtype, order="F")
         s = np.empty((kk, 1), dtype=a.dtype, order="F")
@@ -167,7 +181,7 @@ class Context:
         del keep
         return u, s, vt
 
-    def _rsvd_torch(self, a, k, q, p, seed, omega, sharded=False, qr=None, fused=False, shard_cols=False):
+    def _rsvd_torch(self, a, k, q, p, seed, omega, sharded=False, qr=None, fused=False, shard_cols=False, mixed=None):
         import torch
         if a.dim() != 2:
             raise ValueError("a_mat must be 2-D")
@@ -188,7 +202,7 @@ class Context:
         nt = (m if shard_cols else n) if sharded else min(m, n)
         l = min(k + max(p, 0), nt)
         o, keep = self._opts(seed, omega, nt, l, a.dtype, True, self._qr_flag(qr) | (L.POWER_FUSED if fused else 0) |
-                             (L.SHARD_COLS if shard_cols else 0))
+                             (L.SHARD_COLS if shard_cols else 0) | self._mixed_flag(mixed))
         kk = max(k, 1)
         dev = a.device
         u = torch.empty((kk, m), dtype=a.dtype, device=dev).t()     # (m, k) column-major
@@ -202,7 +216,8 @@ class Context:
         del keep
         return u, s, vt
 
-    def rsvd_sharded(self, a_local, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, fused=False, shard="rows", qr=None):
+    def rsvd_sharded(self, a_local, n_rank, n_iters, n_oversamples, *, seed=None, omega=None, fused=False, shard="rows", qr=None,
+                     mixed=None):
         """Sharded random_svd, one process per GPU.  shard="rows": `a_local` holds this rank's
         rows of a TALL matrix (torch CUDA tensor); returns (U_local, S, Vt) with S, Vt replicated.  shard="cols":
         `a_local` holds this rank's COLUMNS of a FAT matrix; returns (U, S, Vt_local) with U, S replicated
@@ -210,7 +225,7 @@ class Context:
         if shard not in ("rows", "cols"):
             raise ValueError("shard must be 'rows' or 'cols'")
         return self._rsvd_torch(a_local, int(n_rank), int(n_iters), int(n_oversamples), seed, omega, sharded=True, fused=fused,
-                                shard_cols=(shard == "cols"), qr=qr)
+                                shard_cols=(shard == "cols"), qr=qr, mixed=mixed)
 
     # ---- PCA caller (pca_rsvd.rs:56-82) ---------------------------------------------------
     def pca_sharded(self, x_local, rank, n_iter=None, n_oversamples=None, *, seed=None, omega=None, center=None):

@@ -41,6 +41,9 @@ inline RunOpts parse_opts(const corrla_opts* o, bool dev_ptrs) {
   const char* fu_env = std::getenv("CORRLA_POWER_FUSED");
   r.power_fused = fu_env && std::atoi(fu_env) != 0;
   if (const char* pz = std::getenv("CORRLA_TEST_POISON_CORE")) r.poison_core = std::atoi(pz);  // test hook, see RunOpts
+  if (const char* mx = std::getenv("CORRLA_SKETCH_MIXED"))
+    r.mixed_planes = std::strcmp(mx, "bf16x3") == 0 ? 2 : (std::strcmp(mx, "bf16x6") == 0 ? 3 : 0);
+  if (const char* mp = std::getenv("CORRLA_MIXED_PROJECT")) r.mixed_project = std::atoi(mp) != 0;
   if (!o) return r;
   if (o->struct_size != sizeof(corrla_opts)) throw Error(ST_EINVAL, "corrla_opts.struct_size mismatch");
   // seed: used as given when it is non-zero or CORRLA_SEED_EXPLICIT is set (so 0 is a usable seed); otherwise every
@@ -56,6 +59,10 @@ inline RunOpts parse_opts(const corrla_opts* o, bool dev_ptrs) {
   r.pca_center = (o->flags & CORRLA_PCA_CENTER_FUSED) ? 1 : ((o->flags & CORRLA_PCA_CENTER_COPY) ? 2 : 0);
   r.qr_householder = r.qr_householder || (o->flags & CORRLA_QR_HOUSEHOLDER) != 0;
   r.power_fused = r.power_fused || (o->flags & CORRLA_POWER_FUSED) != 0;
+  if ((o->flags & CORRLA_SKETCH_BF16X3) && (o->flags & CORRLA_SKETCH_BF16X6))
+    throw Error(ST_EINVAL, "CORRLA_SKETCH_BF16X3 and CORRLA_SKETCH_BF16X6 are mutually exclusive");
+  if (o->flags & CORRLA_SKETCH_BF16X3) r.mixed_planes = 2;
+  if (o->flags & CORRLA_SKETCH_BF16X6) r.mixed_planes = 3;
   return r;
 }
 
@@ -399,7 +406,7 @@ inline void power_iter_entry(Dev& dev, bool host_ptrs, const T* a, int64_t m, in
 // res = beta * op(A) * X   (mat_utils.rs:20-33 for the two hot-path shapes)
 template <class Dev, class T>
 inline void matmul_entry(Dev& dev, int trans, const T* a, int64_t m, int64_t n, int64_t rs, int64_t cs, const T* x,
-                         int64_t ldx, int64_t l, T beta, T* res, int64_t ldres) {
+                         int64_t ldx, int64_t l, T beta, T* res, int64_t ldres, Timings* tm_out = nullptr) {
   if (!x || !res) throw Error(ST_EINVAL, "x or res is NULL");
   validate_matrix(a, m, n, rs, cs);
   if (l < 1) throw Error(ST_EINVAL, "l must be >= 1");
@@ -408,6 +415,7 @@ inline void matmul_entry(Dev& dev, int trans, const T* a, int64_t m, int64_t n, 
   dev.begin_call();
   TallA<T> ta = stage_input<Dev, T>(dev, false, a, m, n, rs, cs, true);
   RsvdDriver<Dev, T> drv(dev, false);
+  drv.mixed_planes_ = parse_opts(nullptr, true).mixed_planes;  // CORRLA_SKETCH_MIXED (this hook takes no opts)
   Skinny<T> xs = dev.template alloc_skinny<T>(xin, l);
   dev.copy_in_skinny(x, ldx, xs);
   Skinny<T> out = dev.template alloc_skinny<T>(xout, l);
@@ -419,6 +427,7 @@ inline void matmul_entry(Dev& dev, int trans, const T* a, int64_t m, int64_t n, 
     drv.a_times(ta, xs, out, beta_dev);
   dev.copy_out(out, l, res, ldres, false, false);
   dev.end_call();
+  if (tm_out) tm_out->n_mixed_products = drv.tm.n_mixed_products;
 }
 
 }  // namespace corrla

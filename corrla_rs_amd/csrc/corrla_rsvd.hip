@@ -91,7 +91,7 @@ corrla_status matmul_c(corrla_ctx* ctx, int trans, const T* a, int64_t m, int64_
                        int64_t ldx, int64_t l, T beta, T* res, int64_t ldres) {
   return guarded([&] {
     corrla_ctx* c = need(ctx);
-    locked_call(c, [&] { matmul_entry<HipDev, T>(c->dev, trans, a, m, n, rs, cs, x, ldx, l, beta, res, ldres); });
+    locked_call(c, [&] { matmul_entry<HipDev, T>(c->dev, trans, a, m, n, rs, cs, x, ldx, l, beta, res, ldres, &c->last); });
   });
 }
 template <class T>
@@ -119,6 +119,7 @@ corrla_status time_sketch_c(corrla_ctx* ctx, const T* a, int64_t m, int64_t n, i
     dev.begin_call();
     TallA<T> ta = stage_input<HipDev, T>(dev, false, a, m, n, rs, cs, true);
     RsvdDriver<HipDev, T> drv(dev, false);
+    drv.mixed_planes_ = parse_opts(nullptr, true).mixed_planes;  // CORRLA_SKETCH_MIXED (the hook takes no opts)
     Skinny<T> xs = dev.alloc_skinny<T>(n, l);
     dev.copy_in_skinny(x, ldx, xs);
     Skinny<T> out = dev.alloc_skinny<T>(m, l);
@@ -185,6 +186,8 @@ CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings*
     out->collective_bytes = t.collective_bytes;
     out->sketch_kernel_ms = t.sketch_kernel_ms;
     out->host_enqueue_ms = t.host_enqueue_ms;
+    out->n_mixed_products = t.n_mixed_products;
+    out->reserved_ = 0;
   });
 }
 

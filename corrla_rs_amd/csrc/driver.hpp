@@ -104,6 +104,9 @@ struct RunOpts {
   int pca_center = 0;    // 0 default, 1 fused, 2 centred copy (corrla_pca_* only)
   bool qr_householder = false;  // thin-Q by Householder TSQR instead of CholeskyQR2 (CORRLA_QR_HOUSEHOLDER)
   bool power_fused = false;     // one-sweep Z' = A^T (A Z) where it applies (CORRLA_POWER_FUSED)
+  int mixed_planes = 0;         // 0: exact f32 / f64 products; 2 / 3: the tall products of the range finder on the bf16 matrix
+                                // pipe, operands split into 2 ("bf16x3") / 3 ("bf16x6") bf16 pieces, f32 accumulate
+  bool mixed_project = false;   // ... and the projection B = Q^T A (random_svd.rs:80) as well
   int poison_core = 0;          // TEST HOOK (env CORRLA_TEST_POISON_CORE = 1 NaN / 2 inf): one entry of the l x l core of
                                 // random_svd.rs:89 is overwritten before its SVD; the call must end with ST_ENUMERIC
 };
@@ -118,6 +121,7 @@ struct Timings {
   int qr_passes = 0;
   int n_collectives = 0;        // all-reduces issued by this call on this rank (row-sharded entry points)
   double collective_bytes = 0;  // payload bytes of those all-reduces
+  int n_mixed_products = 0;     // tall products that ran on the bf16-split kernels (RunOpts::mixed_planes)
   // breakdown of qr_ms (only filled when phase profiling is on): Gram GEMM, D2H + analysis, host Cholesky /
   // inverse, H2D + apply GEMM
   double qr_gram_ms = 0, qr_down_ms = 0, qr_host_ms = 0, qr_apply_ms = 0;
@@ -149,8 +153,11 @@ struct RsvdDriver {
 
   // ---- op(A) * skinny ---------------------------------------------------------------
   // Y (mt x L) = scale * A * X (nt x L)                         random_svd.rs:31,47-51
+  int mixed_planes_ = 0;  // set from RunOpts while the range finder runs (power_iter), see RunOpts::mixed_planes
   void a_times(const TallA<T>& a, const Skinny<T>& x, Skinny<T>& y, const T* scale_dev) {
-    if (a.row_major)
+    if (mixed_planes_ && dev.template mixed_fits<T>(!a.row_major, a.mem, x, y))
+      dev.gemm_mixed(!a.row_major, a.mem, x, y, scale_dev, mixed_planes_), ++tm.n_mixed_products;
+    else if (a.row_major)
       dev.gemm_nn(a.mem, x, y, scale_dev);
     else
       dev.gemm_tn(a.mem, x, y, scale_dev);
@@ -163,7 +170,9 @@ struct RsvdDriver {
   }
   // Z (nt x L) = scale * A^T * Y (mt x L); all-reduced when rows are sharded   random_svd.rs:42-46,80
   void at_times(const TallA<T>& a, const Skinny<T>& y, Skinny<T>& z, const T* scale_dev, bool sharded) {
-    if (a.row_major)
+    if (mixed_planes_ && dev.template mixed_fits<T>(a.row_major, a.mem, y, z))
+      dev.gemm_mixed(a.row_major, a.mem, y, z, scale_dev, mixed_planes_), ++tm.n_mixed_products;
+    else if (a.row_major)
       dev.gemm_tn(a.mem, y, z, scale_dev);
     else
       dev.gemm_nn(a.mem, y, z, scale_dev);
@@ -695,6 +704,12 @@ struct RsvdDriver {
   int64_t power_iter(const TallA<T>& a, int64_t l, int64_t n_iter, const RunOpts& o, Skinny<T>& y, Skinny<T>& y2) {
     qr_householder = o.qr_householder;
     m_local_ = m_local_override_ >= 0 ? m_local_override_ : a.mt;
+    struct MixedScope {  // the bf16-split products serve the range finder only (random_svd.rs:31, 42-51)
+      int& slot;
+      int saved;
+      MixedScope(int& s, int v) : slot(s), saved(s) { slot = v; }
+      ~MixedScope() { slot = saved; }
+    } mixed_scope(mixed_planes_, o.mixed_planes);
     PhaseTimer pt;
     Skinny<T> om = dev.template alloc_skinny<T>(a.nt, l);
     if (o.omega) {
@@ -919,7 +934,9 @@ struct RsvdDriver {
     PhaseTimer pt;
     // B^T = A^T Q  (n x l)                                                           :80
     Skinny<T> bt = dev.template alloc_skinny<T>(a.nt, l);
+    mixed_planes_ = o.mixed_project ? o.mixed_planes : 0;
     at_times(a, q, bt, kNone, o.sharded);
+    mixed_planes_ = 0;
     phase(tm.project_ms, pt);
     // SVD of B (l x n), :89.  The reference takes faer's full SVD and slices; here:
     // B^T = Qb C with Qb orthonormal (n x l) and C = Qb^T B^T (l x l); C = Uc S Vc^T on the host;

@@ -21,6 +21,7 @@
 #include "jacobi_mc_kernels.hpp"
 #include "ata_kernels.hpp"
 #include "tall_kernels.hpp"
+#include "mixed_kernels.hpp"
 
 namespace corrla {
 
@@ -115,6 +116,7 @@ class HipDev {
     robust_qr_ = env_int("CORRLA_DEVICE_ROBUST_QR", 1) != 0;  // 0: the round-1 optimistic CholeskyQR2 + host-controlled repeat
     persist_max_tiles_ = env_int("CORRLA_GEMM_PERSIST_TILES", 16);  // 0: one workgroup per outer tile everywhere
     gemm_debug_flags_ = env_int("CORRLA_GEMM_DEBUG", 0);  // timing-only ablations, results are wrong
+    if (const char* e = std::getenv("CORRLA_MIXED_MIN_WORK")) mixed_min_work_ = std::atof(e);
   }
   ~HipDev() {
     (void)hipSetDevice(device);
@@ -303,6 +305,129 @@ class HipDev {
   void gemm_tn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale_dev) {
     if (x.rows != r.rows) throw Error(ST_EINVAL, "gemm_tn: inner dimensions differ");
     launch_gemm<T>(true, r, x, out, scale_dev, r.cols, r.rows);
+  }
+
+  // ---- bf16-split tall products (mixed_kernels.hpp): f32 operands, bf16 MFMA, f32 accumulate ----------
+  // np = 2 ("bf16x3": hi hi + hi lo + lo hi) or 3 ("bf16x6").  Serves row-major f32 big operands against one column
+  // block (<= 144 columns) when the product is large enough to be worth the extra launches; everything else keeps the
+  // exact f32 kernels (the caller asks mixed_fits first).
+  template <class T>
+  bool mixed_fits(bool tn, const Big<T>& r, const Skinny<T>& x, const Skinny<T>& out) const {
+    if constexpr (!std::is_same<T, float>::value) {
+      return false;
+    } else {
+      const int64_t outer_n = tn ? r.cols : r.rows, red_n = tn ? r.rows : r.cols;
+      if (x.external || col_blocking(x.cols).nblk != 1) return false;
+      if (((uintptr_t)r.p % 16) || (r.ld % 4) || (r.cols_readable % 4) || ((uintptr_t)x.p % 16) || (x.ld % 64)) return false;
+      if (x.ld < round_up(red_n, k::kMxKT) || out.ld < outer_n || out.rows != outer_n) return false;
+      if ((const void*)r.p == (const void*)x.p) return false;  // Gram products stay exact
+      // (CORRLA_MIXED_MIN_WORK: tests drive small shapes through the kernels)
+      return outer_n >= 1 && red_n >= 1 && (double)outer_n * (double)red_n >= (double)mixed_min_work_;
+    }
+  }
+  template <int NT, int NP, bool TN>
+  void mixed_launch_one(dim3 grid, const k::MxArgs& g) {
+    static bool attr_set = false;  // per instantiation; contexts are created under a process-wide lock
+    const int lds = k::mx_lds_bytes(NT, NP);
+    if (!attr_set) {
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_bf16s_kernel<NT, NP, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((k::gemm_bf16s_kernel<NT, NP, TN>), grid, dim3(64 * (k::kMxWaves + k::kMxLoaders)), lds, stream, g);
+  }
+  template <int NP, bool TN>
+  void mixed_launch_nt(int nt, dim3 grid, const k::MxArgs& g) {
+    switch (nt) {
+      case 1: mixed_launch_one<1, NP, TN>(grid, g); break;
+      case 2: mixed_launch_one<2, NP, TN>(grid, g); break;
+      case 3: mixed_launch_one<3, NP, TN>(grid, g); break;
+      case 4: mixed_launch_one<4, NP, TN>(grid, g); break;
+      case 5: mixed_launch_one<5, NP, TN>(grid, g); break;
+      case 6: mixed_launch_one<6, NP, TN>(grid, g); break;
+      case 7: mixed_launch_one<7, NP, TN>(grid, g); break;
+      case 8: mixed_launch_one<8, NP, TN>(grid, g); break;
+      default: mixed_launch_one<9, NP, TN>(grid, g); break;
+    }
+  }
+  template <class T>
+  void gemm_mixed(bool tn, const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale_dev, int np) {
+    if constexpr (std::is_same<T, float>::value)
+      gemm_mixed_f32(tn, r, x, out, scale_dev, np);
+    else
+      throw Error(ST_EINVAL, "internal: the bf16-split products are f32 only");
+  }
+  void gemm_mixed_f32(bool tn, const Big<float>& r, const Skinny<float>& x, Skinny<float>& out, const float* scale_dev, int np) {
+    if (np != 2 && np != 3) throw Error(ST_EINVAL, "internal: bf16 split takes 2 or 3 planes");
+    if (!mixed_fits<float>(tn, r, x, out)) throw Error(ST_EINVAL, "internal: operands outside the bf16-split kernels' domain");
+    const int64_t outer_n = tn ? r.cols : r.rows, red_n = tn ? r.rows : r.cols;
+    const ColBlocking cb = col_blocking(x.cols);
+    if (cb.cols_alloc > x.cols_alloc || (!out.external && cb.cols_alloc > out.cols_alloc) || (out.external && out.cols < x.cols))
+      throw Error(ST_EINVAL, "internal: skinny column padding too small for the column blocking");
+    // the skinny operand in np bf16 planes, reduction index in MFMA fragment order
+    const int64_t plane_stride = x.ld * cb.cols_alloc;
+    __bf16* planes = (__bf16*)alloc_bytes((size_t)np * (size_t)plane_stride * 2);
+    {
+      const int64_t slots = plane_stride / 8;
+      const dim3 sg((unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (slots + 255) / 256)));
+      if (np == 3)
+        hipLaunchKernelGGL((k::split_planes_kernel<3>), sg, dim3(256), 0, stream, (const float*)x.p, x.ld, cb.cols_alloc, planes, plane_stride, run_if_);
+      else
+        hipLaunchKernelGGL((k::split_planes_kernel<2>), sg, dim3(256), 0, stream, (const float*)x.p, x.ld, cb.cols_alloc, planes, plane_stride, run_if_);
+      CORRLA_HIP(hipGetLastError());
+    }
+    const int64_t tiles64 = (red_n + k::kMxKT - 1) / k::kMxKT;
+    if (tiles64 > 0x7fffffff) throw Error(ST_EINVAL, "reduction dimension too large");
+    const int tiles_total = (int)tiles64;
+    const int64_t outer_tiles = (outer_n + k::kMxOuter - 1) / k::kMxOuter;
+    if (outer_tiles > 0x7fffffff) throw Error(ST_EINVAL, "outer dimension too large");
+    // one workgroup per CU (120-155 KB of LDS): split the reduction until the grid fills the chip
+    int nsplit = 1;
+    if (outer_tiles < num_cus) nsplit = (int)std::min<int64_t>((num_cus + outer_tiles / 2) / outer_tiles, std::max(1, tiles_total / 16));
+    if (const int ov = env_int("CORRLA_MIXED_SPLIT", 0)) nsplit = ov;
+    nsplit = std::max(1, std::min(std::min(nsplit, tiles_total), 65535));
+    k::MxArgs a;
+    a.r = r.p;
+    a.r_rows = r.rows;
+    a.r_cols = r.cols;
+    a.r_ld = r.ld;
+    a.r_cols_readable = r.cols_readable;
+    a.planes = planes;
+    a.x_ld = x.ld;
+    a.plane_stride = plane_stride;
+    a.out = out.p;
+    a.out_ld = out.ld;
+    a.out_cols = out.external ? out.cols : cb.cols_alloc;
+    a.slab = nullptr;
+    a.slab_stride = (int64_t)out.ld * cb.cols_alloc;
+    if (nsplit > 1) a.slab = (float*)alloc_bytes((size_t)nsplit * (size_t)a.slab_stride * sizeof(float));
+    a.scale = scale_dev;
+    a.zero = (const float*)zero_page_;
+    a.tiles_total = tiles_total;
+    a.tiles_per_split = (tiles_total + nsplit - 1) / nsplit;
+    a.nsplit = nsplit;
+    a.run_if = run_if_;
+    a.vec_store = ((out.ld % 4) == 0 && ((uintptr_t)out.p % 16) == 0) ? 1 : 0;
+    const dim3 grid((unsigned)outer_tiles, 1, (unsigned)nsplit);
+    check_grid(grid);
+    if (np == 3) {
+      if (tn) mixed_launch_nt<3, true>(cb.nt, grid, a); else mixed_launch_nt<3, false>(cb.nt, grid, a);
+    } else {
+      if (tn) mixed_launch_nt<2, true>(cb.nt, grid, a); else mixed_launch_nt<2, false>(cb.nt, grid, a);
+    }
+    CORRLA_HIP(hipGetLastError());
+    if (nsplit >= 8) {
+      dim3 rg((unsigned)((outer_n + 63) / 64), (unsigned)cb.cols_alloc);
+      check_grid(rg);
+      hipLaunchKernelGGL((k::slab_reduce_deep_kernel<float>), rg, dim3(256), 0, stream, (const float*)a.slab, a.slab_stride, nsplit,
+                         out.p, out.ld, outer_n, a.out_cols, scale_dev, run_if_);
+      CORRLA_HIP(hipGetLastError());
+    } else if (nsplit > 1) {
+      dim3 rg((unsigned)((outer_n + 255) / 256), (unsigned)cb.cols_alloc);
+      check_grid(rg);
+      hipLaunchKernelGGL((k::slab_reduce_kernel<float>), rg, dim3(256), 0, stream, (const float*)a.slab, a.slab_stride, nsplit,
+                         out.p, out.ld, outer_n, a.out_cols, scale_dev, run_if_);
+      CORRLA_HIP(hipGetLastError());
+    }
   }
 
   // ---- one-sweep Z' = A^T (A Z) (ata_kernels.hpp): row-major f32 A with n <= 512, l <= 80 -----------
@@ -1387,6 +1512,7 @@ class HipDev {
   int jmc_extra_sweeps_ = 0, jmc_sweeps_hint_ = 0;
   bool jmc_force_v_ = false;
   int64_t tall_min_rows_ = 65536;
+  double mixed_min_work_ = 16777216.0;  // outer x reduction elements below which a product keeps the exact kernels
 
   static void check_grid(const dim3& g) {
     if (g.y > 65535u || g.z > 65535u) throw Error(ST_EINVAL, "problem too large for the launch grid");

@@ -87,6 +87,15 @@ typedef enum corrla_status {
  * is this block transposed (a stride swap).  Outputs: U m x rank and S replicated on every rank, Vt rank x n_local =
  * this rank's columns of V^T.  opts->omega, when given, is m x l (the short side). */
 #define CORRLA_SHARD_COLS 0x40u
+/* Mixed-precision range finder (f32 row-major inputs, l <= 144; ignored elsewhere): the tall
+ * products of power_iter (random_svd.rs:31, 42-51: Y = A Omega, Z = A^T Y, Y = A Z) run on the bf16 matrix units with
+ * an f32 accumulator, each f32 operand split on the fly into bf16 pieces whose products are exact in f32:
+ *   BF16X6: three pieces (24 bits), six products -- the f32 product to f32 rounding at 16/6 of the exact-f32 MFMA rate;
+ *   BF16X3: two pieces (16 bits), three products -- relative error 2^-16 per product, twice that rate again.
+ * The thin-Q, the projection B = Q^T A (random_svd.rs:80), the core SVD and U = Q U~ stay in exact f32.  Off by default;
+ * the environment variable CORRLA_SKETCH_MIXED=bf16x3|bf16x6 sets it for every call.  Mutually exclusive. */
+#define CORRLA_SKETCH_BF16X3 0x80u
+#define CORRLA_SKETCH_BF16X6 0x100u
 
 /*
  * Options block.  Zero-initialise, set struct_size = sizeof(corrla_opts).  NULL opts == defaults.
@@ -123,6 +132,8 @@ typedef struct corrla_timings {
                               context's stream around Y = A*Omega (no extra synchronisation) */
   double host_enqueue_ms;  /* host wall clock spent enqueueing the call: the host runs ahead of the device */
   double collective_bytes; /* payload bytes of those all-reduces (n x l factors, l x l Gram matrices, scalars) */
+  int32_t n_mixed_products; /* tall products of this call that ran on the bf16-split kernels (CORRLA_SKETCH_BF16X3 / X6) */
+  int32_t reserved_;
 } corrla_timings;
 
 /* ---- library / context ------------------------------------------------------------- */

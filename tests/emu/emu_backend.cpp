@@ -167,6 +167,11 @@ class EmuDev {
       for (int64_t kk = 0; kk < a.cols; ++kk) z.p[c * z.ld + kk] = (T)acc[(size_t)kk];
     }
   }
+  // the bf16-split products exist on the GPU only: the emulation keeps every product exact (the flags are accepted)
+  template <class T>
+  bool mixed_fits(bool, const Big<T>&, const Skinny<T>&, const Skinny<T>&) const { return false; }
+  template <class T>
+  void gemm_mixed(bool, const Big<T>&, const Skinny<T>&, Skinny<T>&, const T*, int) { throw Error(ST_EINVAL, "emu: no bf16-split products"); }
   template <class T>
   void allreduce(T* p, size_t count) {
     if (g_nranks <= 1) return;

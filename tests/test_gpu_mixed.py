@@ -1,0 +1,145 @@
+"""GPU tests of the bf16-split tall products (csrc/mixed_kernels.hpp; off by default): exact-integer layout
+checks of both kernels for every column-tile count and both piece counts, accuracy against f64 on Gaussian data, and the
+whole random_svd with the option on against the oracle with the SAME gates as the exact-f32 path.  Run with -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import rsvd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    """A context whose bf16-split kernels also take small products (the size threshold is read at creation)."""
+    import corrla_rs_amd as cr
+    old = os.environ.get("CORRLA_MIXED_MIN_WORK")
+    os.environ["CORRLA_MIXED_MIN_WORK"] = "1"
+    try:
+        c = cr.Context(0)
+    finally:
+        if old is None:
+            del os.environ["CORRLA_MIXED_MIN_WORK"]
+        else:
+            os.environ["CORRLA_MIXED_MIN_WORK"] = old
+    yield c
+    c.close()
+
+
+def _matmul(ctx, torch, a, x, trans, mode, monkeypatch):
+    if mode:
+        monkeypatch.setenv("CORRLA_SKETCH_MIXED", mode)
+    else:
+        monkeypatch.delenv("CORRLA_SKETCH_MIXED", raising=False)
+    res = ctx.matmul(torch.tensor(a, device="cuda"), torch.tensor(x, device="cuda"), trans=trans)
+    took_mixed = ctx.timings()["n_mixed_products"]
+    monkeypatch.delenv("CORRLA_SKETCH_MIXED", raising=False)
+    assert took_mixed == (1 if mode else 0), (mode, took_mixed)
+    return res.cpu().numpy()
+
+
+# (rows of A, columns of A, columns of the skinny operand): every column-tile count 1..9, row / reduction tails
+_SHAPES = [(256, 32, 16), (300, 70, 5), (1000, 600, 138), (257, 33, 144), (513, 1030, 17), (2048, 96, 40), (700, 257, 49),
+           (64, 4100, 64), (4100, 64, 81), (1500, 520, 100), (1024, 1024, 113), (33, 8, 128)]
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("trans", [False, True])
+@pytest.mark.parametrize("shape", _SHAPES)
+def test_bf16_split_products_exact_on_small_integers(ctx, torch, monkeypatch, shape, trans, mode):
+    """Integers in [-8, 8] are exact in bf16 and their dot products exact in the f32 accumulator, so the result must be
+    the integer product bit for bit: any slip in the fragment maps, swizzles, tails or the slab reduction shows."""
+    m, n, l = shape
+    rng = np.random.default_rng(m * 7 + n * 3 + l)
+    a = rng.integers(-8, 9, size=(m, n)).astype(np.float32)
+    x = rng.integers(-8, 9, size=((m if trans else n), l)).astype(np.float32)
+    got = _matmul(ctx, torch, a, x, trans, mode, monkeypatch)
+    want = (a.T.astype(np.float64) @ x if trans else a.astype(np.float64) @ x)
+    assert got.shape == want.shape
+    assert np.array_equal(got.astype(np.float64), want), float(np.max(np.abs(got - want)))
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_bf16_split_accuracy_on_gaussian_data(ctx, torch, monkeypatch, trans):
+    """bf16x6 carries 24 bits per operand: as accurate as the exact-f32 kernel.  bf16x3 carries 16: ~2^-17 per product."""
+    rng = np.random.default_rng(5)
+    m, n, l = 3000, 2100, 138
+    a = rng.standard_normal((m, n)).astype(np.float32)
+    x = rng.standard_normal(((m if trans else n), l)).astype(np.float32)
+    truth = a.T.astype(np.float64) @ x if trans else a.astype(np.float64) @ x
+    err = {}
+    for mode in (None, "bf16x6", "bf16x3"):
+        got = _matmul(ctx, torch, a, x, trans, mode, monkeypatch)
+        err[mode] = float(np.linalg.norm(got - truth) / np.linalg.norm(truth))
+    print("relative Frobenius error vs f64:", err)
+    assert err["bf16x6"] <= max(2.0 * err[None], 3e-7)
+    assert 5e-7 < err["bf16x3"] < 3e-5
+
+
+def test_bf16_split_handles_scales_and_signed_zeros(ctx, torch, monkeypatch):
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((600, 300)).astype(np.float32)
+    x = rng.standard_normal((300, 20)).astype(np.float32)
+    a[::7] = 0.0
+    a[5, :] = -0.0
+    for sa, sx in ((1e-12, 1e12), (1e15, 1e-3), (1e-18, 1.0)):
+        got = _matmul(ctx, torch, a * np.float32(sa), x * np.float32(sx), False, "bf16x6", monkeypatch)
+        truth = (a.astype(np.float64) * sa) @ (x.astype(np.float64) * sx)
+        assert np.linalg.norm(got - truth) <= 5e-7 * np.linalg.norm(truth)
+
+
+def _spectrum_matrix(rng, m, n, decay):
+    if decay is None:
+        return rng.standard_normal((m, n)).astype(np.float32)
+    u, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    v, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    return ((u * (decay ** np.arange(n))) @ v.T).astype(np.float32)
+
+
+@pytest.mark.parametrize("decay", [None, 0.9, 0.7])
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+def test_random_svd_with_the_mixed_range_finder_holds_the_f32_gates(ctx, mode, decay):
+    """Same A, same Omega, GPU with the option on vs the f32 oracle: |d relerr| <= 1e-5 (north star) and
+    max |dS| <= 2e-5 sigma_1 -- the gates of the exact-f32 path (tests/test_gpu_parity.py: _parity)."""
+    rng = np.random.default_rng(17)
+    m, n, k, q, p = 4096, 1024, 128, 2, 10
+    a = _spectrum_matrix(rng, m, n, decay)
+    om = rng.standard_normal((n, k + p)).astype(np.float32)
+    u, s, vt = ctx.rsvd(a, k, q, p, omega=om, mixed=mode)
+    assert ctx.timings()["n_mixed_products"] == 1 + 2 * q
+    uo, so, vto = orc.random_svd(a, k, q, p, omega=om)
+    u0, s0, vt0 = ctx.rsvd(a, k, q, p, omega=om)
+    ds = float(np.max(np.abs(s.ravel().astype(np.float64) - so.ravel())) / so[0, 0])
+    ds0 = float(np.max(np.abs(s0.ravel().astype(np.float64) - so.ravel())) / so[0, 0])
+    dre = abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto))
+    dre0 = abs(orc.relerr(a, u0, s0, vt0) - orc.relerr(a, uo, so, vto))
+    print(f"{mode} decay={decay}: dS/s1 {ds:.2e} (exact path {ds0:.2e}), |d relerr| {dre:.2e} (exact path {dre0:.2e})")
+    eps = np.finfo(np.float32).eps
+    assert np.max(np.abs(u.T.astype(np.float64) @ u - np.eye(k))) <= 200 * eps * np.sqrt(m)
+    assert dre <= 1e-5
+    assert ds <= (2e-5 if decay is None else 2e-3)     # decaying spectra: the exact path's own tolerance
+
+
+def test_mixed_flag_is_ignored_outside_its_domain(ctx, torch):
+    """f64 inputs, column-major inputs and sketches wider than one column block keep the exact products."""
+    rng = np.random.default_rng(3)
+    a64 = rng.standard_normal((1200, 300))
+    om = rng.standard_normal((300, 40))
+    u, s, vt = ctx.rsvd(a64, 30, 2, 10, omega=om, mixed="bf16x6")
+    assert ctx.timings()["n_mixed_products"] == 0
+    uo, so, vto = orc.random_svd(a64, 30, 2, 10, omega=om)
+    assert np.max(np.abs(s - so)) <= 1e-10 * so[0, 0]
+    a32 = rng.standard_normal((1200, 400)).astype(np.float32)
+    ctx.rsvd(a32, 150, 1, 10, mixed="bf16x6")                       # l = 160: two column blocks
+    assert ctx.timings()["n_mixed_products"] == 0
+    with pytest.raises(ValueError):
+        ctx.rsvd(a32, 10, 1, 4, mixed="fp8")

@@ -138,3 +138,48 @@ def test_sharded_handshake_and_empty_shard_world_size_1(torch, monkeypatch):
     ue, se, vte = c.rsvd_sharded(e, 12, 2, 8, omega=om)
     assert ue.shape == (0, 12) and float(se.abs().max()) == 0.0 and bool(torch.isfinite(vte).all())
     c.close()
+
+
+# ---- the rank-deficient f32 cases round 2's fuzz sweep left outside its 2e-3 bound --------------------------------------
+# All five are exactly rank-deficient f32 inputs with q = 3: the reference schedule runs its first three power iterations
+# without any re-orthonormalisation (random_svd.rs:37), the sketch's columns spread like (sigma_1 / sigma_r)^7 > 1 / eps_f32,
+# and the trailing directions of range(A) are rounding noise in EVERY f32 implementation of the schedule -- including the
+# reference's own arithmetic: the CPU restatement run in f32 (LAPACK Householder QR, exactly the reference's algorithm) is
+# itself 3e-3 .. 9e-3 away from the f64 oracle in relerr on these inputs (measured: gpurun_out/r03_batch1/replay.log,
+# DESIGN section 4).  The sweep compared f32 results with the f64 oracle at 2e-3, which no f32 run can hold here; what CAN
+# be held, and is tested, is that the GPU path loses no more than the reference algorithm does in the same arithmetic:
+#   deviation_gpu(f64 oracle)  <=  max(2e-3, 3 x deviation_cpu_f32(f64 oracle))  for S,   2 x  for relerr.
+# (The Householder thin-Q does NOT help: measured 1.3 - 1.8 x further from the oracle than the default path on every
+#  one of these cases; 61:757 and 62:373 are the two the sweep had drawn in Householder mode and run in it here too.)
+_RANKDEF_CASES = [(12, 416, False), (32, 420, True), (51, 426, True), (61, 757, False), (62, 373, False)]
+
+
+@pytest.mark.parametrize("seed,want,wide", _RANKDEF_CASES)
+def test_rank_deficient_f32_fuzz_cases_lose_no_more_than_the_reference_algorithm_in_f32(ctx, seed, want, wide):
+    from tools.fuzz_parity import cases
+    hit = None
+    for case, a, om, k, q, p, l, kind, dtype, hh in cases(want + 1, seed, wide):
+        if case == want:
+            hit = (a, om, k, q, p, l, kind, dtype, hh)
+    assert hit is not None
+    a, om, k, q, p, l, kind, dtype, hh = hit
+    assert dtype == np.float32 and kind == "rankdef" and q == 3
+    ref = orc.random_svd(a.astype(np.float64), k, q, p, omega=om.astype(np.float64))
+    cpu32 = orc.random_svd(a, k, q, p, omega=om)
+
+    def dev(usv):
+        u, s, vt = usv
+        ds = float(np.max(np.abs(s.ravel().astype(np.float64) - ref[1].ravel())) / ref[1][0, 0])
+        return ds, abs(orc.relerr(a, u, s, vt) - orc.relerr(a, *ref))
+
+    ds_cpu, re_cpu = dev(cpu32)
+    gpu = ctx.rsvd(a, k, q, p, omega=om, qr="householder" if hh else None)
+    ds_gpu, re_gpu = dev(gpu)
+    print(f"{seed}:{want} l={l}: dS gpu {ds_gpu:.2e} cpu-f32 {ds_cpu:.2e}; |d relerr| gpu {re_gpu:.2e} cpu-f32 {re_cpu:.2e}")
+    assert np.all(np.isfinite(gpu[1])) and np.all(np.diff(gpu[1].ravel()) <= 1e-6 * gpu[1][0, 0])
+    assert ds_gpu <= max(2e-3, 3.0 * ds_cpu)
+    assert re_gpu <= max(2e-3, 2.0 * re_cpu)
+    # the factors themselves stay orthonormal over the numerically non-null triplets
+    keep = ref[1].ravel() > 1e-4 * ref[1][0, 0]
+    uu = gpu[0][:, keep].astype(np.float64)
+    assert np.max(np.abs(uu.T @ uu - np.eye(uu.shape[1]))) <= 2e-3
