@@ -407,6 +407,7 @@ class HipDev {
     a.nsplit = nsplit;
     a.run_if = run_if_;
     a.vec_store = ((out.ld % 4) == 0 && ((uintptr_t)out.p % 16) == 0) ? 1 : 0;
+    a.debug_flags = gemm_debug_flags_;
     const dim3 grid((unsigned)outer_tiles, 1, (unsigned)nsplit);
     check_grid(grid);
     if (np == 3) {

@@ -128,6 +128,7 @@ struct MxArgs {
   int tiles_total, tiles_per_split, nsplit;
   const int* run_if;
   int vec_store;
+  int debug_flags;       // timing-only ablations (wrong results): 2 = no plane DMA, 4 = no big-operand DMA after the first tile
 };
 
 // swizzles of the two LDS images (both applied on the DMA's per-lane SOURCE address and again on the read):
@@ -231,6 +232,10 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
       for (int i = 0; i < DPL; ++i) {
         const int c = lw + kMxLoaders * i;
         if (c < NBIG) {
+          if ((g.debug_flags & 4) && kt > t_begin + NSTAGE) {
+            glds16(g.zero, scratch);
+            continue;
+          }
           const float* src;
           if constexpr (!TN) {
             const int row = 8 * c + (lane >> 3);
@@ -245,6 +250,10 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
           }
           glds16(src, st + c * 1024);
         } else if (c < NCH) {
+          if ((g.debug_flags & 2) && kt > t_begin + NSTAGE) {
+            glds16(g.zero, scratch);
+            continue;
+          }
           const int cc = c - NBIG;
           const int p = cc / NT, ct = cc - p * NT;
           const int row = 16 * ct + (lane >> 2);

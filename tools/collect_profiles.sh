@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence of a round into gpurun_out/prof_$TAG (run on the MI355X box from the repo root):
 #   kernel-trace + stats of the default bench, one-step timelines (C2, C4 shard, C3), PMC passes on the tall GEMMs
 #   (f32 C2 sketch, f64 C3 sketch; counters in separate passes, never combined with other trace domains).
-# Usage: bash tools/collect_profiles.sh r02 [what...]   what: bench tl_c2 tl_c4 tl_c3 pmc_f32 pmc_f64 (default: all)
+# Usage: bash tools/collect_profiles.sh r03 [what...]   what: bench tl_c2 tl_c4 tl_c3 pmc_f32 pmc_f64 (default: these) pmc_c4 pmc_x6 pmc_x3 pmc_c4_x6
 set -u
 TAG=${1:-r02}; shift || true
 WHAT=${*:-bench tl_c2 tl_c4 tl_c3 pmc_f32 pmc_f64}
@@ -28,19 +28,25 @@ if has tl_c3; then
   python3 $REPO/tools/step_timeline.py $(find $OUT/tl_c3 -name '*.db' | head -1) --call 4 > $OUT/step_timeline_c3.txt 2>&1
   python3 $REPO/tools/step_timeline.py $(find $OUT/tl_c3 -name '*.db' | head -1) --stats > $OUT/kernel_stats_c3.txt 2>&1
 fi
-pmc() {  # $1 = f32|f64
-  local dt=$1; local sum=$OUT/pmc_${dt}_gemm_summary.txt; : > $sum
-  local arg=""; [[ $dt == f64 ]] && arg="f64"
+pmc() {  # $1 = f32|f64|c4 [$2 = bf16x6|bf16x3 -> summary pmc_mixed_<mode>_...]
+  local dt=$1; local mx=${2:-}; local tag=$dt; [[ -n "$mx" ]] && tag=mixed_${mx}_$dt
+  local sum=$OUT/pmc_${tag}_gemm_summary.txt; : > $sum
+  local arg="$dt $mx"
   for pass in "sq:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
               "lds:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS" \
               "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
     local name=${pass%%:*}; local ctrs=${pass#*:}
-    rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc_${dt}_$name -o $name -- python3 $REPO/tools/profile_sketch.py 40 $arg > $OUT/pmc_${dt}_$name.log 2>&1
+    rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc_${tag}_$name -o $name -- python3 $REPO/tools/profile_sketch.py 40 $arg > $OUT/pmc_${tag}_$name.log 2>&1
     echo "## pass pmc_$name" >> $sum
-    python3 $REPO/tools/summarize_pmc.py $(find $OUT/pmc_${dt}_$name -name '*counter_collection.csv' | head -1) gemm >> $sum 2>&1
-    python3 $REPO/tools/summarize_pmc.py $(find $OUT/pmc_${dt}_$name -name '*counter_collection.csv' | head -1) slab_reduce >> $sum 2>&1
+    python3 $REPO/tools/summarize_pmc.py $(find $OUT/pmc_${tag}_$name -name '*counter_collection.csv' | head -1) gemm >> $sum 2>&1
+    python3 $REPO/tools/summarize_pmc.py $(find $OUT/pmc_${tag}_$name -name '*counter_collection.csv' | head -1) slab_reduce >> $sum 2>&1
+    python3 $REPO/tools/summarize_pmc.py $(find $OUT/pmc_${tag}_$name -name '*counter_collection.csv' | head -1) split_planes >> $sum 2>&1
   done
 }
 has pmc_f32 && pmc f32
 has pmc_f64 && pmc f64
+has pmc_c4 && pmc c4
+has pmc_x6 && pmc f32 bf16x6
+has pmc_x3 && pmc f32 bf16x3
+has pmc_c4_x6 && pmc c4 bf16x6
 ls -la $OUT | head -40
