@@ -7,6 +7,7 @@
 #include "capi_impl.hpp"
 #include "hip_backend.hpp"
 #include "grad_kernels.hpp"
+#include "knn2_kernels.hpp"
 
 using namespace corrla;
 
@@ -299,8 +300,46 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     if (n_q > 0x7fffffff) throw Error(ST_EINVAL, "too many query points for one launch");
     // Both kernels spend ~n_nbrs ln(n_pts / n_nbrs) list insertions per query; the MFMA distance tile only pays off
     // once the scan itself dominates (measured: 5e4 points 0.10 s VALU / 0.14 s MFMA, 1e5 0.28 / 0.30, 2e5 0.93 / 0.45)
-    const int knn_mode = env_int("CORRLA_KNN", 0);  // 1: VALU kernel, 2: MFMA kernel, 0: by size
-    if (knn_mode == 1 || (knn_mode == 0 && n_pts < 131072)) {
+    const int knn_mode = env_int("CORRLA_KNN", 0);  // 1: VALU kernel, 2: f32-MFMA kernel, 3: bf16-filter kernel, 0: by size
+    // knn2_kernels.hpp (round 3): bf16x3 MFMA filter + batched bitonic list merges; n_nbrs <= 128.  Small clouds keep the
+    // VALU scan (its per-query lists live in LDS and there is too little work to amortise the split of the cloud).
+    const bool knn2 = (knn_mode == 3 || (knn_mode == 0 && n_pts >= 8192)) && nn <= k::kK2List;
+    if (knn2) {
+      const int S = kk <= 32 ? 1 : 2;
+      const int64_t nchunks = (n_pts + k::kK2Chunk - 1) / k::kK2Chunk;
+      __bf16* pb = (__bf16*)dev.alloc_bytes((size_t)nchunks * (size_t)k::k2_chunk_bytes(S));
+      float* pnf = (float*)dev.alloc_bytes((size_t)nchunks * k::kK2Chunk * sizeof(float));
+      double* mean = (double*)dev.alloc_bytes(64 * sizeof(double));
+      const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n_pts + 4095) / 4096));
+      const int64_t rpb = (n_pts + nb - 1) / nb;
+      double* partial = (double*)dev.alloc_bytes((size_t)nb * 64 * sizeof(double));
+      hipLaunchKernelGGL(k::knn2_colsum_kernel, dim3((unsigned)nb), dim3(256), 0, dev.stream, xd, n_pts, kk, rpb, partial);
+      hipLaunchKernelGGL(k::knn2_mean_kernel, dim3(1), dim3(64), 0, dev.stream, (const double*)partial, nb, n_pts, kk, mean);
+      hipLaunchKernelGGL(k::knn2_prep_kernel, dim3((unsigned)nchunks), dim3(256), 0, dev.stream, xd, n_pts, kk, (const double*)mean, S,
+                         pb, pnf);
+      k::Knn2Args ka;
+      ka.pb = pb;
+      ka.pn = pnf;
+      ka.x = xd;
+      ka.xq = qd;
+      ka.mean = mean;
+      ka.n_pts = n_pts;
+      ka.n_q = n_q;
+      ka.nchunks = nchunks;
+      ka.ntiles = (n_q + k::kK2Q - 1) / k::kK2Q;
+      ka.k = kk;
+      ka.n_nbrs = nn;
+      const int64_t wgs = std::min<int64_t>(ka.ntiles, (int64_t)dev.num_cus * std::max(1, env_int("CORRLA_KNN2_WGS_PER_CU", 2)));
+      ka.cand = (int*)dev.alloc_bytes((size_t)wgs * k::kK2Q * k::kK2Cap * sizeof(int));
+      ka.list_d = (double*)dev.alloc_bytes((size_t)wgs * k::kK2Q * k::kK2List * sizeof(double));
+      ka.list_i = (int*)dev.alloc_bytes((size_t)wgs * k::kK2Q * k::kK2List * sizeof(int));
+      ka.nbr = nbr;
+      if (S == 1)
+        hipLaunchKernelGGL((k::knn2_kernel<1>), dim3((unsigned)wgs), dim3(64 * k::kK2Waves), k::k2_lds_bytes(1), dev.stream, ka);
+      else
+        hipLaunchKernelGGL((k::knn2_kernel<2>), dim3((unsigned)wgs), dim3(64 * k::kK2Waves), k::k2_lds_bytes(2), dev.stream, ka);
+      CORRLA_HIP(hipGetLastError());
+    } else if (knn_mode == 1 || (knn_mode == 0 && n_pts < 131072)) {
       const size_t lds_knn = k::knn_lds_bytes(kk, nn);
       const int64_t knn_blocks = (n_q + k::kKnnQueries - 1) / k::kKnnQueries;
       hipLaunchKernelGGL(k::knn_kernel, dim3((unsigned)knn_blocks), dim3(64 * k::kKnnWaves), lds_knn, dev.stream, (const double*)xt,

@@ -1,0 +1,376 @@
+// Exact k-nearest-neighbour scan of the active-subspace gradient stage, second generation (SURVEY 8 f2;
+// PolyGradientEstimator::nearest_points, src/lib_math_utils/active_subspaces.rs:86-97): same results as
+// knn_mfma_kernel (grad_kernels.hpp) -- the n nearest support points of every query by squared Euclidean distance in
+// f64, equal distances by lower index -- at a fraction of its time.  What round 2's kernel spent (1e6 x 64, 80
+// neighbours, 4.6 s for the stage): 64 f32 MFMAs per 64-point chunk and wave (2048 of ~5500 cycles per chunk), two
+// workgroup barriers per chunk with one wave per SIMD, and ~755 wave-serial list insertions per query at ~1.3 us each.
+//
+// Here:
+//  * FILTER on the bf16 matrix pipe: d^2(q, p) = |q|^2 + |p|^2 - 2 q.p with q.p from v_mfma_f32_16x16x32_bf16, both
+//    operands split into two bf16 pieces of the CENTRED coordinates (hi hi + hi lo + lo hi: 2^-16 relative per product;
+//    distances are translation invariant, and centring keeps |q|^2 + |p|^2 -- which the rounding error scales with --
+//    as small as the data allow): 24 MFMAs of 16 cycles per chunk and wave instead of 64 of 32.  The support points are
+//    split ONCE (knn2_prep_kernel) into MFMA B-fragment order, so a chunk is 16 KiB of linear LDS-DMA and every fragment
+//    read is one conflict-free ds_read_b128.  A pair passes when  d^2_filter - margin (|q|^2 + |p|^2) < tau_q  (tau_q = the
+//    query's current n-th exact distance; margin 2e-4 bounds every rounding of the filter) -- conservative, never exact.
+//  * SURVIVORS are only appended (4-byte index, ballot + popcount, no sorting) to a per-query candidate buffer.
+//  * FLUSHES are batched and ALIGNED: after chunks 1, 2, 4, 8, ... (the expected number of survivors per query between
+//    chunk c and 2c is n ln 2) every wave empties the buffers of its 16 queries at the same time -- the waves of a
+//    workgroup share every staged chunk, so a flush that stalled one of them would stall them all.  A flush takes 64
+//    candidates at a time, lane = candidate: exact f64 distance from the uncentred rows, a 64-key bitonic sort of
+//    (distance, index), and a two-stage bitonic merge into the query's sorted list of 128 -- ~40 compare-exchange steps
+//    for 64 candidates instead of 64 serial insertions.  A buffer that fills between flush points flushes on the spot.
+//  * 8 scanning waves (128 queries) per workgroup, two or more workgroups per CU, persistent over the query tiles.
+// The neighbour SETS are exact whatever the filter does (a pair the filter drops is farther than the n-th exact
+// distance by more than the bound on the filter's error); the ORDER inside a set is (exact distance, index).
+// Limits: k <= 64, n_nbrs <= 128 (the host falls back to knn_mfma_kernel beyond).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "mixed_kernels.hpp"
+
+namespace corrla {
+namespace k {
+
+constexpr int kK2Waves = 8;             // scanning waves per workgroup
+constexpr int kK2Q = 16 * kK2Waves;     // queries per workgroup tile
+constexpr int kK2Cap = 256;             // candidate slots per query between flushes
+constexpr int kK2List = 128;            // list entries per query (n_nbrs <= 128)
+constexpr int kK2Chunk = 64;            // support points per chunk
+constexpr float kK2Margin = 2.0e-4f;    // bound on |d^2_filter - d^2| / (|q|^2 + |p|^2), see the header
+
+__host__ __device__ constexpr int k2_chunk_bytes(int s) { return s * 8192; }            // s = 32-dimension MFMA steps
+__host__ __device__ constexpr int k2_stage_bytes(int s) { return k2_chunk_bytes(s) + 256; }  // + 64 f32 norms
+__host__ __device__ constexpr int k2_lds_bytes(int s) { return 2 * k2_stage_bytes(s); }
+
+struct Knn2Args {
+  const __bf16* pb;   // [chunk][s][plane (hi, lo)][tile t of 16 points][lane][8]: B fragments of the centred points
+  const float* pn;    // [chunk][64]: |x_p - mean|^2 rounded to f32; +inf for the padding points of the last chunk
+  const double* x;    // support points, row-major n_pts x k
+  const double* xq;   // queries, row-major n_q x k
+  const double* mean; // [k]
+  int64_t n_pts, n_q, nchunks, ntiles;
+  int k, n_nbrs;
+  int* cand;          // [gridDim.x][kK2Q][kK2Cap]
+  double* list_d;     // [gridDim.x][kK2Q][kK2List]
+  int* list_i;        // [gridDim.x][kK2Q][kK2List]
+  int* nbr;           // out: [n_q][n_nbrs], nearest first
+};
+
+// column means of x (n x k row-major), two stages in fixed order: partial[b][d] = sum over the rows of block b
+__global__ __launch_bounds__(256) void knn2_colsum_kernel(const double* __restrict__ x, int64_t n, int k, int64_t rows_per_block,
+                                                          double* partial) {
+  __shared__ double red[256];
+  const int d = threadIdx.x & 63, sub = threadIdx.x >> 6;  // 4 row phases x 64 dimensions
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+  double s = 0.0;
+  if (d < k)
+    for (int64_t r = r0 + sub; r < r1; r += 4) s += x[r * k + d];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sub == 0 && d < k) partial[(int64_t)blockIdx.x * 64 + d] = (red[d] + red[64 + d]) + (red[128 + d] + red[192 + d]);
+}
+__global__ void knn2_mean_kernel(const double* partial, int nblocks, int64_t n, int k, double* mean) {
+  const int d = threadIdx.x;
+  if (d >= 64) return;
+  double s = 0.0;
+  if (d < k)
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 64 + d];
+  mean[d] = d < k ? s / (double)n : 0.0;
+}
+
+// one 256-thread block per chunk of 64 points: centred coordinates -> two bf16 pieces in B-fragment order, + norms.
+// Fragment of v_mfma_f32_16x16x32_bf16: lane (col = lane & 15, g = lane >> 4) holds B[k = 8 g + j][col], j = 0..7.
+__global__ __launch_bounds__(256) void knn2_prep_kernel(const double* __restrict__ x, int64_t n_pts, int k, const double* __restrict__ mean,
+                                                        int nsteps, __bf16* pb, float* pn) {
+  const int64_t c = blockIdx.x;
+  const int tid = threadIdx.x;
+  __bf16* dst = pb + c * (int64_t)(nsteps * 8192 / 2);
+  for (int item = tid; item < nsteps * 4 * 64; item += 256) {  // (s, t, lane)
+    const int lane = item & 63, t = (item >> 6) & 3, s = item >> 8;
+    const int64_t p = c * kK2Chunk + 16 * t + (lane & 15);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = 32 * s + 8 * (lane >> 4) + j;
+      v[j] = (p < n_pts && d < k) ? (float)(x[p * k + d] - mean[d]) : 0.0f;
+    }
+    // (the f32 rounding of the centred coordinate, 2^-24 relative, is part of the margin)
+    bf16x8 fr[2];
+    mx_split8<2>(v, fr);
+    *(bf16x8*)(dst + ((s * 2 + 0) * 4 + t) * 512 + lane * 8) = fr[0];
+    *(bf16x8*)(dst + ((s * 2 + 1) * 4 + t) * 512 + lane * 8) = fr[1];
+  }
+  if (tid < kK2Chunk) {
+    const int64_t p = c * kK2Chunk + tid;
+    float out = __builtin_huge_valf();
+    if (p < n_pts) {
+      double s2 = 0.0;
+      for (int d = 0; d < k; ++d) {
+        const double df = x[p * k + d] - mean[d];
+        s2 += df * df;
+      }
+      out = (float)s2;
+    }
+    pn[c * kK2Chunk + tid] = out;
+  }
+}
+
+// ---- (distance, index) keys across the 64 lanes ----------------------------------------------------------------------
+struct K2Key {
+  double d;
+  int i;
+};
+__device__ __forceinline__ bool k2_less(const K2Key& a, const K2Key& b) { return a.d < b.d || (a.d == b.d && a.i < b.i); }
+__device__ __forceinline__ K2Key k2_shfl_xor(const K2Key& a, int m) {
+  K2Key r;
+  r.d = __shfl_xor(a.d, m, 64);
+  r.i = __shfl_xor(a.i, m, 64);
+  return r;
+}
+__device__ __forceinline__ K2Key k2_shfl(const K2Key& a, int src) {
+  K2Key r;
+  r.d = __shfl(a.d, src, 64);
+  r.i = __shfl(a.i, src, 64);
+  return r;
+}
+// a bitonic sequence over the lanes -> ascending
+__device__ __forceinline__ void k2_bitonic_merge(K2Key& a, int lane) {
+#pragma unroll
+  for (int j = 32; j >= 1; j >>= 1) {
+    const K2Key o = k2_shfl_xor(a, j);
+    const bool lower = (lane & j) == 0;
+    if (k2_less(o, a) == lower) a = o;  // lower lane keeps the smaller key, upper lane the larger
+  }
+}
+// any sequence -> ascending
+__device__ __forceinline__ void k2_sort(K2Key& a, int lane) {
+#pragma unroll
+  for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+    for (int j = kk >> 1; j >= 1; j >>= 1) {
+      const K2Key o = k2_shfl_xor(a, j);
+      const bool up = (lane & kk) == 0 || kk == 64;
+      const bool lower = (lane & j) == 0;
+      if (k2_less(o, a) == (lower == up)) a = o;
+    }
+  }
+}
+
+template <int S>
+__global__ __launch_bounds__(64 * kK2Waves, 2) void knn2_kernel(Knn2Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STG = k2_stage_bytes(S);
+  constexpr int NDMA = S * 8;  // 1 KiB LDS-DMA instructions per chunk (fragments); + one 256-byte one for the norms
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int kdim = g.k;
+  int* const cand_w = g.cand + ((int64_t)blockIdx.x * kK2Q + wave * 16) * kK2Cap;
+  double* const ld_w = g.list_d + ((int64_t)blockIdx.x * kK2Q + wave * 16) * kK2List;
+  int* const li_w = g.list_i + ((int64_t)blockIdx.x * kK2Q + wave * 16) * kK2List;
+  const double inf = __builtin_huge_val();
+
+  auto stage = [&](int buf, int64_t c) __attribute__((always_inline)) {
+    char* st = smem + buf * STG;
+    const char* src = (const char*)g.pb + c * (int64_t)k2_chunk_bytes(S);
+#pragma unroll
+    for (int i = wave; i < NDMA; i += kK2Waves) glds16(src + i * 1024 + lane * 16, st + i * 1024);
+    if (wave == (NDMA % kK2Waves))
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.pn + c * kK2Chunk + lane),
+                                       (__attribute__((address_space(3))) void*)(st + k2_chunk_bytes(S)), 4, 0, 0);
+  };
+
+  for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    const int64_t q0 = tile * kK2Q + wave * 16;  // this wave's 16 queries
+    // ---- A fragments: query q0 + fr, dimensions 32 s + 8 fg + j, centred, two bf16 pieces; |q - mean|^2 ----
+    bf16x8 ah[S], al[S];
+    float qn_mine = 0.f;
+    {
+      const bool qv = q0 + fr < g.n_q;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int d = 32 * s + 8 * fg + j;
+          v[j] = (qv && d < kdim) ? (float)(g.xq[(q0 + fr) * kdim + d] - g.mean[d]) : 0.0f;
+          qn_mine += v[j] * v[j];
+        }
+        bf16x8 f2[2];
+        mx_split8<2>(v, f2);
+        ah[s] = f2[0];
+        al[s] = f2[1];
+      }
+      qn_mine += __shfl_xor(qn_mine, 16, 64);
+      qn_mine += __shfl_xor(qn_mine, 32, 64);  // every lane with this fr now holds |q_fr|^2 (f32: inside the margin)
+    }
+    // D layout: column (point) = lane & 15, row (query) = 4 fg + r
+    // (ext-vector registers with constant indices: plain arrays captured by the flush lambdas ended up in scratch)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    f32x4 qn_r, tau_r;
+    i32x4 cnt_r;
+    unsigned qvalid = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      qn_r[r] = __shfl(qn_mine, 4 * fg + r, 64);
+      tau_r[r] = __builtin_huge_valf();
+      cnt_r[r] = 0;
+      if (q0 + 4 * fg + r < g.n_q) qvalid |= 0x1111u << r;  // bit 4 t + r for every t
+    }
+    // empty lists
+    for (int e = lane; e < 16 * kK2List; e += 64) {
+      __hip_atomic_store(ld_w + e, inf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(li_w + e, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // batch-merge the candidates of local query qi (uniform) into its list; returns the new n-th distance
+    auto flush_query = [&](int qi, int ncand) __attribute__((always_inline)) -> double {
+      const int64_t q = q0 + qi;
+      K2Key l0, l1;
+      l0.d = __hip_atomic_load(ld_w + qi * kK2List + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      l0.i = __hip_atomic_load(li_w + qi * kK2List + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      l1.d = __hip_atomic_load(ld_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      l1.i = __hip_atomic_load(li_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double* qp = g.xq + q * kdim;
+      for (int b0 = 0; b0 < ncand; b0 += 64) {
+        K2Key c;
+        c.d = inf;
+        c.i = 0x7fffffff;
+        if (b0 + lane < ncand) {
+          c.i = __hip_atomic_load(cand_w + qi * kK2Cap + b0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double* pp = g.x + (int64_t)c.i * kdim;
+          double s0 = 0.0, s1 = 0.0;
+          int d = 0;
+          for (; d + 1 < kdim; d += 2) {
+            const double a0 = pp[d] - qp[d], a1 = pp[d + 1] - qp[d + 1];
+            s0 += a0 * a0;
+            s1 += a1 * a1;
+          }
+          if (d < kdim) {
+            const double a0 = pp[d] - qp[d];
+            s0 += a0 * a0;
+          }
+          c.d = s0 + s1;
+          if (!(c.d == c.d)) c.d = inf;  // a non-finite distance sorts last, like numpy's argsort of a NaN
+        }
+        k2_sort(c, lane);
+        // the 64 smallest of L1 and the candidates (ascending with descending: the elementwise minimum is bitonic) ...
+        K2Key m = k2_shfl(c, 63 - lane);
+        if (k2_less(l1, m)) m = l1;
+        k2_bitonic_merge(m, lane);
+        // ... then L0 against them: minima = the new L0, maxima = the new L1
+        const K2Key rm = k2_shfl(m, 63 - lane);
+        K2Key lo = l0, hi = rm;
+        if (k2_less(rm, l0)) {
+          lo = rm;
+          hi = l0;
+        }
+        k2_bitonic_merge(lo, lane);
+        k2_bitonic_merge(hi, lane);
+        l0 = lo;
+        l1 = hi;
+      }
+      __hip_atomic_store(ld_w + qi * kK2List + lane, l0.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(li_w + qi * kK2List + lane, l0.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ld_w + qi * kK2List + 64 + lane, l1.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(li_w + qi * kK2List + 64 + lane, l1.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int nn = g.n_nbrs;
+      return nn <= 64 ? __shfl(l0.d, nn - 1, 64) : __shfl(l1.d, nn - 65, 64);
+    };
+    // flush every query of this wave whose buffer holds at least `least` candidates
+    auto flush_wave = [&](int least) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's candidate stores have left it
+#pragma unroll 1
+      for (int qi = 0; qi < 16; ++qi) {
+        const int r = qi & 3, gq = qi >> 2;
+        const int mine = r == 0 ? cnt_r[0] : (r == 1 ? cnt_r[1] : (r == 2 ? cnt_r[2] : cnt_r[3]));
+        const int nc = __shfl(mine, 16 * gq, 64);
+        if (nc < least || nc == 0) continue;  // uniform
+        const double tau = flush_query(qi, nc);
+        // the filter compares in f32: round the threshold UP (never below the exact n-th distance)
+        float tf = (float)tau;
+        if ((double)tf < tau) tf = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, tf) + 1u);  // tau >= 0: next float up
+        if (fg == gq) {
+          if (r == 0) { tau_r[0] = tf; cnt_r[0] = 0; }
+          if (r == 1) { tau_r[1] = tf; cnt_r[1] = 0; }
+          if (r == 2) { tau_r[2] = tf; cnt_r[2] = 0; }
+          if (r == 3) { tau_r[3] = tf; cnt_r[3] = 0; }
+        }
+      }
+    };
+
+    if (g.nchunks > 0) stage(0, 0);
+    for (int64_t c = 0; c < g.nchunks; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of chunk c has landed
+      __syncthreads();                                    // chunk c is complete; every wave is done with chunk c - 1
+      if (c + 1 < g.nchunks) stage((int)((c + 1) & 1), c + 1);
+      const char* st = smem + (int)(c & 1) * STG;
+      f32x4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 bh = *(const bf16x8*)(st + ((s * 2 + 0) * 4 + t) * 1024 + lane * 16);
+          const bf16x8 bl = *(const bf16x8*)(st + ((s * 2 + 1) * 4 + t) * 1024 + lane * 16);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, acc[t], 0, 0, 0);
+        }
+      unsigned hits = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float pnv = *(const float*)(st + k2_chunk_bytes(S) + (16 * t + fr) * 4);  // +inf for padding points
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float nsum = qn_r[r] + pnv;
+          const float dm = __builtin_fmaf(-2.0f, acc[t][r], nsum);
+          const float lim = __builtin_fmaf(kK2Margin, nsum, tau_r[r]);
+          // the negated comparison lets a NaN through to the exact re-check; padding points (nsum = inf) never pass
+          if (!(dm >= lim) && pnv < __builtin_huge_valf()) hits |= 1u << (4 * t + r);
+        }
+      }
+      hits &= qvalid;
+      if (__any(hits != 0)) {
+        const int base = (int)(c * kK2Chunk);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool h = (hits >> (4 * t + r)) & 1u;
+            const unsigned long long m = __ballot(h);
+            if (m == 0) continue;  // uniform
+            const unsigned gm = (unsigned)(m >> (16 * fg)) & 0xffffu;  // the 16 points of MY query (4 fg + r)
+            const int slot = cnt_r[r] + __popc(gm & ((1u << fr) - 1u));
+            if (h && slot < kK2Cap) cand_w[(4 * fg + r) * kK2Cap + slot] = base + 16 * t + fr;
+            cnt_r[r] += __popc(gm);
+          }
+      }
+      // aligned flush points: after chunks 1, 2, 4, 8, ... and the last one; in between only a buffer that could
+      // overflow in the next chunk (64 more candidates) is flushed
+      const int64_t done = c + 1;
+      const bool point = (done & (done - 1)) == 0 || done == g.nchunks;
+      const int cmax = max(max(cnt_r[0], cnt_r[1]), max(cnt_r[2], cnt_r[3]));
+      // (one call site: the per-query registers above stay registers only if the flush code is inlined once)
+      const int least = point ? 1 : (__any(cmax > kK2Cap - kK2Chunk) ? kK2Cap - kK2Chunk + 1 : 0);
+      if (least) flush_wave(least);
+    }
+    // ---- results: the first n_nbrs entries of every list, nearest first ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (int qi = 0; qi < 16; ++qi) {
+      const int64_t q = q0 + qi;
+      if (q >= g.n_q) break;  // uniform
+      for (int e = lane; e < g.n_nbrs; e += 64)
+        g.nbr[q * g.n_nbrs + e] = __hip_atomic_load(li_w + qi * kK2List + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // the stage buffers are free for the next tile
+  }
+}
+
+}  // namespace k
+}  // namespace corrla

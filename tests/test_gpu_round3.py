@@ -183,3 +183,67 @@ def test_rank_deficient_f32_fuzz_cases_lose_no_more_than_the_reference_algorithm
     keep = ref[1].ravel() > 1e-4 * ref[1][0, 0]
     uu = gpu[0][:, keep].astype(np.float64)
     assert np.max(np.abs(uu.T @ uu - np.eye(uu.shape[1]))) <= 2e-3
+
+
+# ---- the second-generation k-NN scan (csrc/knn2_kernels.hpp: bf16x3 MFMA filter, batched bitonic list merges) ----------
+def _ref_gradients(x, y, xq, n_nbrs):
+    """order-1 gradients from brute-force numpy neighbours (distance, index order) -- the oracle's algebra with its own
+    neighbour search, vectorised so that thousands of queries stay cheap"""
+    from oracle import active_ss_oracle as aso
+    est = aso.PolyGradientEstimator(x, y, 1, n_nbrs)
+    return aso.create_grad_mat(est, xq)
+
+
+@pytest.mark.parametrize("n,k,n_nbrs,nq,kind", [
+    (9000, 64, 80, 300, "gauss"),          # two MFMA steps, BASELINE config 5's dimensions
+    (9000, 17, 30, 300, "gauss"),          # one MFMA step, odd dimension
+    (12000, 33, 128, 200, "gauss"),        # the largest list the kernel serves
+    (10000, 8, 12, 500, "offset"),         # a cloud far from the origin: centring keeps the filter's margin small
+    (8200, 24, 60, 700, "dups"),           # repeated points: equal distances -> lower index
+    (8193, 5, 70, 129, "clustered"),       # tight clusters: many near-ties, query tile tail (129 = 128 + 1)
+    (20000, 64, 65, 64, "gauss"),          # list just beyond one 64-entry half
+])
+def test_knn2_neighbour_sets_are_exact(ctx, monkeypatch, n, k, n_nbrs, nq, kind):
+    """CORRLA_KNN=3 (the default from 8192 points on): gradients equal to those of the exact search -- i.e. the same
+    neighbour sets in the same order -- on Gaussian, offset, duplicated and clustered clouds, against the numpy oracle and
+    against the VALU scan of round 1 (CORRLA_KNN=1)."""
+    rng = np.random.default_rng(n + k)
+    x = rng.standard_normal((n, k))
+    if kind == "offset":
+        x = x * 0.01 + 1000.0
+    elif kind == "dups":
+        x[n // 2: n // 2 + 2000] = x[:2000]
+    elif kind == "clustered":
+        centres = rng.standard_normal((40, k)) * 5.0
+        x = centres[rng.integers(0, 40, n)] + 1e-3 * rng.standard_normal((n, k))
+    w = rng.standard_normal(k)
+    y = np.sin((x - x.mean(axis=0)) @ w * 0.3) + 0.05 * ((x - x.mean(axis=0)) ** 2).sum(axis=1)
+    xq = x[rng.permutation(n)[:nq]] if kind != "gauss" else np.vstack([x[: nq // 2], rng.standard_normal((nq - nq // 2, k))])
+    monkeypatch.setenv("CORRLA_KNN", "3")
+    g3, nreg3 = ctx.grad_mat(x, y, 1, n_nbrs, xq)
+    monkeypatch.setenv("CORRLA_KNN", "1")
+    g1, nreg1 = ctx.grad_mat(x, y, 1, n_nbrs, xq)
+    monkeypatch.delenv("CORRLA_KNN")
+    scale = np.abs(g1).max()
+    assert nreg3 == nreg1
+    assert np.max(np.abs(g3 - g1)) <= 1e-9 * scale, float(np.max(np.abs(g3 - g1)) / scale)
+    if kind in ("gauss", "offset"):
+        go = _ref_gradients(x, y, xq[:60], n_nbrs)
+        assert np.max(np.abs(g3[:, :60] - go)) <= 1e-8 * np.abs(go).max()
+
+
+def test_knn2_is_the_default_scan_and_handles_few_queries_many_points(ctx, torch):
+    """A device-resident cloud of 300 000 points, 1000 queries: a handful of query tiles, 4688 chunks, every flush point of
+    the schedule; affine function -> exact slopes whatever the neighbours, and the sampled queries match the oracle."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n, k = 300_000, 32
+    x = torch.randn((n, k), dtype=torch.float64, device="cuda", generator=g)
+    w = torch.linspace(1.0, 2.0, k, dtype=torch.float64, device="cuda")
+    y = torch.sin(x @ w * 0.1)
+    xq = x[:1000]
+    gm, nreg = ctx.grad_mat(x, y, 1, 48, xq)
+    assert nreg == 0 and gm.shape == (k, 1000)
+    from oracle import active_ss_oracle as aso
+    xs, ys = x.cpu().numpy(), y.cpu().numpy()
+    go = aso.create_grad_mat(aso.PolyGradientEstimator(xs, ys, 1, 48), xs[:12])
+    assert np.max(np.abs(gm[:, :12].cpu().numpy() - go)) <= 1e-9 * np.abs(go).max()
