@@ -106,7 +106,7 @@ struct RunOpts {
   bool power_fused = false;     // one-sweep Z' = A^T (A Z) where it applies (CORRLA_POWER_FUSED)
   int mixed_planes = 0;         // 0: exact f32 / f64 products; 2 / 3: the tall products of the range finder on the bf16 matrix
                                 // pipe, operands split into 2 ("bf16x3") / 3 ("bf16x6") bf16 pieces, f32 accumulate
-  bool mixed_project = false;   // ... and the projection B = Q^T A (random_svd.rs:80) as well
+  bool mixed_project = true;    // ... and the projection B = Q^T A (random_svd.rs:80) as well (CORRLA_MIXED_PROJECT=0: exact)
   int poison_core = 0;          // TEST HOOK (env CORRLA_TEST_POISON_CORE = 1 NaN / 2 inf): one entry of the l x l core of
                                 // random_svd.rs:89 is overwritten before its SVD; the call must end with ST_ENUMERIC
 };
@@ -738,8 +738,7 @@ struct RsvdDriver {
         dev.ata_fused(a.mem, i == 0 ? om : z, z);
         if (i == 0) dev.event_mark(1);
         if (o.sharded) dev.allreduce(z.p, (size_t)z.ld * (size_t)z.cols_alloc);
-        dev.sumsq(z, ss_dev);
-        dev.rsqrt_scalar(ss_dev, inv_dev);
+        dev.inv_norm(z, ss_dev, inv_dev);
         dev.scale_inplace(z, inv_dev);
         if (i == 0) phase(tm.sketch_ms, pt);
       }
@@ -764,8 +763,7 @@ struct RsvdDriver {
       // instead of sigma_1^3 (a wider safe range than the reference's own), no pass over the m-sized Y is spent on
       // the norm or the scaling (two sweeps of 3.2 GB each per iteration at 10^7 x 80), and sharded runs need no
       // scalar all-reduce (Z is already all-reduced).
-      dev.sumsq(z, ss_dev);
-      dev.rsqrt_scalar(ss_dev, inv_dev);
+      dev.inv_norm(z, ss_dev, inv_dev);
       dev.scale_inplace(z, inv_dev);
       a_times(a, z, y, kNone);              // :47-51
     }

@@ -386,13 +386,15 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
                                                       double* g, int64_t ldg, int* status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int P = order == 1 ? k + 1 : k + k * (k + 1) / 2 + 1;  // design columns (the constant is the last one)
-  const int LM = P + 1;                                        // row pitch of M (the right-hand side is column P)
+  const int LM = (P + 1) | 1;                 // row pitch of M (the right-hand side is column P): ODD, so that the 64 rows
+                                              // the lanes of the factorisation walk in step fall in different banks
   double* xn = (double*)smem;                 // [n_nbrs][k] neighbour coordinates minus x0
   double* yn = xn + (size_t)n_nbrs * k;       // [n_nbrs]
   double* M = yn + n_nbrs;                    // [P][LM] normal equations, lower triangle -> Cholesky factor
   double* x0 = M + (size_t)P * LM;            // [k]
   double* beta = x0 + k;                      // [P]
-  int* pa = (int*)(beta + P);                 // [P] column -> (a, b); b = -1: linear term a; a = -1: constant
+  double* dinv = beta + P;                    // [P] 1 / L(i, i)
+  int* pa = (int*)(dinv + P);                 // [P] column -> (a, b); b = -1: linear term a; a = -1: constant
   int* pb = pa + P;
   int* flag = pb + P;
   const int lane = threadIdx.x;
@@ -488,38 +490,62 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
     M[i * LM + j] = gram_entry(i, j);
   }
   __syncthreads();
-  // Cholesky (lower, in place) with a relative pivot test; a failed pivot restarts once with a ridge
+  // Cholesky (lower, in place) with a relative pivot test; a failed pivot restarts once with a ridge.
+  // LEFT-looking (Crout), lane = row: column j is  L(i, j) = (M(i, j) - sum_{p < j} L(i, p) L(j, p)) / L(j, j)  for the rows
+  // i >= j -- every lane runs the same j-long dot product over its own row (odd pitch: conflict-free) against the
+  // broadcast row j, one barrier per column and no read-modify-write of the trailing matrix.  (Round 2's right-looking
+  // form spent ~1.5 us per pivot on its unbalanced rank-1 update and two more barriers: ~100 us of a 460-us query.)
   double dmax = 0.0;
   for (int i = 0; i < P; ++i) dmax = fmax(dmax, M[i * LM + i]);
   double ridge = 0.0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     bool ok = true;
-    // right-looking: after step j the trailing lower triangle holds M - L(:, :j+1) L(:, :j+1)^T; lane = column, so the
-    // lanes of a wave read consecutive addresses of one row (no LDS bank conflicts) and L(i, j) is a broadcast
     for (int j = 0; j < P; ++j) {
-      const double piv = M[j * LM + j] + ridge;
-      if (!(piv > 1e-13 * dmax)) {
+      const double* rj = M + j * LM;
+      double sjj = 0.0;  // the pivot, formed redundantly by every lane (uniform control flow, no broadcast needed)
+      {
+        double t0 = 0.0, t1 = 0.0;
+        int p2 = 0;
+        for (; p2 + 1 < j; p2 += 2) {
+          t0 += rj[p2] * rj[p2];
+          t1 += rj[p2 + 1] * rj[p2 + 1];
+        }
+        if (p2 < j) t0 += rj[p2] * rj[p2];
+        sjj = rj[j] + ridge - (t0 + t1);
+      }
+      if (!(sjj > 1e-13 * dmax)) {
         ok = false;
         break;  // uniform
       }
-      const double ljj = sqrt(piv), inv = 1.0 / ljj;
-      __syncthreads();
-      for (int i = j + lane; i < P; i += 64) M[i * LM + j] = (i == j) ? ljj : M[i * LM + j] * inv;
-      __syncthreads();
-      for (int c = j + 1 + lane; c < P; c += 64) {
-        const double lcj = M[c * LM + j];
-        int i = c;
-        // four rows at a time with all eight loads issued first: written as a plain read-modify-write loop the compiler
-        // must assume the store to M(i, c) aliases the next load and waits out one LDS round trip per row
-        for (; i + 3 < P; i += 4) {
-          const double a0 = M[i * LM + j], a1 = M[(i + 1) * LM + j], a2 = M[(i + 2) * LM + j], a3 = M[(i + 3) * LM + j];
-          const double m0 = M[i * LM + c], m1 = M[(i + 1) * LM + c], m2 = M[(i + 2) * LM + c], m3 = M[(i + 3) * LM + c];
-          M[i * LM + c] = m0 - a0 * lcj;
-          M[(i + 1) * LM + c] = m1 - a1 * lcj;
-          M[(i + 2) * LM + c] = m2 - a2 * lcj;
-          M[(i + 3) * LM + c] = m3 - a3 * lcj;
+      // 1 / sqrt(pivot): hardware estimate + two Newton steps (the IEEE sqrt and division sequences cost more than the
+      // whole dot product of a column)
+      double rinv = __builtin_amdgcn_rsq(sjj);
+      rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
+      rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
+      auto col_entry = [&](int i) -> double {
+        const double* ri = M + i * LM;
+        double t0 = 0.0, t1 = 0.0;
+        int p2 = 0;
+        for (; p2 + 1 < j; p2 += 2) {
+          t0 += ri[p2] * rj[p2];
+          t1 += ri[p2 + 1] * rj[p2 + 1];
         }
-        for (; i < P; ++i) M[i * LM + c] -= M[i * LM + j] * lcj;
+        if (p2 < j) t0 += ri[p2] * rj[p2];
+        return (ri[j] - (t0 + t1)) * rinv;
+      };
+      // rows j + 1 + lane and + 64 (P <= 129 covers order 2 up to k = 14) are held back until every lane has read the
+      // old column; longer columns write their further rows at once (no other lane reads a row that is not its own)
+      const int i0 = j + 1 + lane, i1 = i0 + 64;
+      double c0 = 0.0, c1 = 0.0;
+      if (i0 < P) c0 = col_entry(i0);
+      if (i1 < P) c1 = col_entry(i1);
+      for (int i = i1 + 64; i < P; i += 64) M[i * LM + j] = col_entry(i);
+      __syncthreads();  // every read of row j (the pivot's old value included) is done
+      if (i0 < P) M[i0 * LM + j] = c0;
+      if (i1 < P) M[i1 * LM + j] = c1;
+      if (lane == 0) {
+        M[j * LM + j] = sjj * rinv;  // L(j, j)
+        dinv[j] = rinv;
       }
       __syncthreads();
     }
@@ -544,21 +570,23 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
   __syncthreads();
   const int fl = *flag;
   if (fl != 2) {
-    // L z = rhs (forward), L^T beta = z (backward); one unknown at a time, dot products across the lanes
+    // L z = rhs, L^T beta = z in the COLUMN-oriented form: once an unknown is known its multiple of column i of L (of
+    // row i for the transposed solve) leaves the remaining right-hand side, lane = row -- no reductions and no divisions
+    // (round 2 took a 64-lane f64 reduction and an IEEE division per unknown: ~200 us per query)
+    for (int r = lane; r < P; r += 64) beta[r] = M[r * LM + P];
+    __syncthreads();
     for (int i = 0; i < P; ++i) {
-      double s = 0.0;
-      for (int c = lane; c < i; c += 64) s += M[i * LM + c] * beta[c];
-      s = wave_sum_f64(s);
+      const double zi = beta[i] * dinv[i];
       __syncthreads();
-      if (lane == 0) beta[i] = (M[i * LM + P] - s) / M[i * LM + i];
+      if (lane == 0) beta[i] = zi;
+      for (int r = i + 1 + lane; r < P; r += 64) beta[r] -= M[r * LM + i] * zi;
       __syncthreads();
     }
     for (int i = P - 1; i >= 0; --i) {
-      double s = 0.0;
-      for (int c = i + 1 + lane; c < P; c += 64) s += M[c * LM + i] * beta[c];
-      s = wave_sum_f64(s);
+      const double bi = beta[i] * dinv[i];
       __syncthreads();
-      if (lane == 0) beta[i] = (beta[i] - s) / M[i * LM + i];
+      if (lane == 0) beta[i] = bi;
+      for (int r = lane; r < i; r += 64) beta[r] -= M[i * LM + r] * bi;
       __syncthreads();
     }
   }
@@ -574,7 +602,8 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
 }
 inline size_t grad_fit_lds_bytes(int k, int n_nbrs, int order) {
   const int P = order == 1 ? k + 1 : k + k * (k + 1) / 2 + 1;
-  return ((size_t)n_nbrs * k + n_nbrs + (size_t)P * (P + 1) + k + P) * 8 + (size_t)(2 * P + 4 + n_nbrs) * 4 + 64;
+  const int LM = (P + 1) | 1;
+  return ((size_t)n_nbrs * k + n_nbrs + (size_t)P * LM + k + 2 * P) * 8 + (size_t)(2 * P + 4 + n_nbrs) * 4 + 64;
 }
 
 }  // namespace k

@@ -1342,15 +1342,8 @@ class HipDev {
   // sign convention: flip (u_i, v_i) so the largest-magnitude entry of v_i is positive
   template <class T>
   void fix_signs(Skinny<T>& v_ref, Skinny<T>& other, int64_t k) {
-    T* sg = (T*)alloc_bytes(sizeof(T) * (size_t)k);
-    hipLaunchKernelGGL((k::column_sign_kernel<T>), dim3((unsigned)k), dim3(256), 0, stream, (const T*)v_ref.p, v_ref.ld,
-                       v_ref.rows, sg);
-    dim3 g1((unsigned)std::min<int64_t>(64, (v_ref.rows + 255) / 256), (unsigned)k);
-    hipLaunchKernelGGL((k::apply_column_sign_kernel<T>), g1, dim3(256), 0, stream, v_ref.p, v_ref.ld, v_ref.rows,
-                       (const T*)sg);
-    dim3 g2((unsigned)std::min<int64_t>(1024, (other.rows + 255) / 256), (unsigned)k);
-    hipLaunchKernelGGL((k::apply_column_sign_kernel<T>), g2, dim3(256), 0, stream, other.p, other.ld, other.rows,
-                       (const T*)sg);
+    hipLaunchKernelGGL((k::column_sign_apply_kernel<T>), dim3((unsigned)k), dim3(256), 0, stream, v_ref.p, v_ref.ld, v_ref.rows,
+                       other.p, other.ld, other.rows);
     CORRLA_HIP(hipGetLastError());
   }
   template <class T>
@@ -1376,6 +1369,16 @@ class HipDev {
     double* partial = (double*)alloc_bytes(sizeof(double) * blocks);
     hipLaunchKernelGGL((k::sumsq_partial_kernel<T>), dim3(blocks), dim3(256), 0, stream, y.p, n, partial);
     hipLaunchKernelGGL(k::sum_partials_kernel, dim3(1), dim3(64), 0, stream, partial, blocks, out_dev);
+    CORRLA_HIP(hipGetLastError());
+  }
+  // ss_dev <- sum of squares of y, inv_dev <- 1 / sqrt(ss): the partial sums and ONE finishing launch
+  template <class T>
+  void inv_norm(const Skinny<T>& y, double* ss_dev, T* inv_dev) {
+    const int64_t n = y.ld * y.cols_alloc;  // padding is zero
+    const int blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + 255) / 256));
+    double* partial = (double*)alloc_bytes(sizeof(double) * blocks);
+    hipLaunchKernelGGL((k::sumsq_partial_kernel<T>), dim3(blocks), dim3(256), 0, stream, y.p, n, partial);
+    hipLaunchKernelGGL((k::sum_partials_rsqrt_kernel<T>), dim3(1), dim3(64), 0, stream, (const double*)partial, blocks, ss_dev, inv_dev);
     CORRLA_HIP(hipGetLastError());
   }
   template <class T>

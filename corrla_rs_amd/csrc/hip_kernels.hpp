@@ -806,6 +806,17 @@ __global__ void sum_partials_kernel(const double* partial, int n, double* out) {
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (threadIdx.x == 0) *out = s;
 }
+// sum of the block partials and 1 / sqrt of it in one launch (the Z-side rescale of every power iteration)
+template <class T>
+__global__ void sum_partials_rsqrt_kernel(const double* partial, int n, double* ss_out, T* inv_out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (threadIdx.x == 0) {
+    *ss_out = s;
+    *inv_out = (T)(s > 0.0 ? 1.0 / sqrt(s) : 0.0);
+  }
+}
 template <class T>
 __global__ void rsqrt_scalar_kernel(const double* ss, T* out) {
   const double v = *ss;
@@ -2688,10 +2699,12 @@ __global__ void rank1_sub_kernel(T* out, int64_t ld, int64_t rows, const T* __re
 // largest-magnitude component (first one on ties) of column i of the SHORT-side factor V_tall (n_t rows,
 // replicated on every rank of a sharded run) is positive.  One workgroup per column finds the sign, then
 // both factors are flipped.
+// One workgroup per column finds the sign and flips its column of both factors (one launch: round 2 used a sign kernel
+// and two apply kernels, 27 us of the C2 step's tail).
 template <class T>
-__global__ void column_sign_kernel(const T* v, int64_t ld, int64_t rows, T* sign_out) {
+__global__ __launch_bounds__(256) void column_sign_apply_kernel(T* v, int64_t ld, int64_t rows, T* other, int64_t ld_o, int64_t rows_o) {
   const int j = blockIdx.x;
-  const T* col = v + (int64_t)j * ld;
+  T* col = v + (int64_t)j * ld;
   T best = (T)-1;
   int64_t best_i = 0;
   for (int64_t i0 = threadIdx.x; i0 < rows; i0 += 4 * (int64_t)blockDim.x) {  // four loads in flight
@@ -2703,13 +2716,14 @@ __global__ void column_sign_kernel(const T* v, int64_t ld, int64_t rows, T* sign
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (a[u] > best) {  // increasing i: the first maximum wins, as before
+      if (a[u] > best) {  // increasing i: the first maximum wins
         best = a[u];
         best_i = i0 + u * (int64_t)blockDim.x;
       }
   }
   __shared__ T sb[256];
   __shared__ int64_t si[256];
+  __shared__ int flip;
   sb[threadIdx.x] = best;
   si[threadIdx.x] = best_i;
   __syncthreads();
@@ -2724,15 +2738,12 @@ __global__ void column_sign_kernel(const T* v, int64_t ld, int64_t rows, T* sign
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) sign_out[j] = (sb[0] > (T)0 && col[si[0]] < (T)0) ? (T)-1 : (T)1;
-}
-template <class T>
-__global__ void apply_column_sign_kernel(T* m, int64_t ld, int64_t rows, const T* sign) {
-  const int j = blockIdx.y;
-  const T sg = sign[j];
-  if (sg > (T)0) return;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x)
-    m[(int64_t)j * ld + i] = -m[(int64_t)j * ld + i];
+  if (threadIdx.x == 0) flip = (sb[0] > (T)0 && col[si[0]] < (T)0) ? 1 : 0;
+  __syncthreads();
+  if (!flip) return;
+  for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) col[i] = -col[i];
+  T* oc = other + (int64_t)j * ld_o;
+  for (int64_t i = threadIdx.x; i < rows_o; i += blockDim.x) oc[i] = -oc[i];
 }
 
 // ---- layout helpers --------------------------------------------------------------------------

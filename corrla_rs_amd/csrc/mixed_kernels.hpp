@@ -295,17 +295,24 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
   for (int i = 0; i < nk; ++i) {
     wg_barrier();  // matches the loaders' barrier: tile i is in LDS
     const char* st = smem + buf * STAGE;
-    bf16x8 af[kMxRowTiles][NP];
+    // Schedule of one tile (everything below is one basic block; round 3 measured the first version -- both splits, then
+    // nine groups of [3 LDS reads, wait, 12 MFMAs] -- at 55 % matrix-pipe occupancy with NO DMA at all: the two waves of a
+    // SIMD run in step, so both split, then both wait on LDS):
+    //   raw reads of both row tiles and the plane fragments of the first T1 column tiles go out together;
+    //   split row tile 0; its products over column tiles 0 .. T1-1 (fragments stay in registers) cover the split of row
+    //   tile 1 -- VALU and MFMA issue side by side, 2 VALU slots per 16-cycle MFMA; then row tile 1 over the same
+    //   fragments; the remaining column tiles read their fragments one tile ahead of their MFMAs.
+    constexpr int T1 = NT < 4 ? NT : 4;
+    float xr[kMxRowTiles][8];
 #pragma unroll
     for (int mw = 0; mw < kMxRowTiles; ++mw) {
-      float x[8];
       if constexpr (!TN) {
         const f32x4 v0 = *(const f32x4*)(st + (a_base + mw * 2048));
         const f32x4 v1 = *(const f32x4*)(st + ((a_base + mw * 2048) ^ 64u));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          x[j] = v0[j];
-          x[4 + j] = v1[j];
+          xr[mw][j] = v0[j];
+          xr[mw][4 + j] = v1[j];
         }
       } else {
 #pragma unroll
@@ -313,18 +320,49 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
           // reduction row kmap(8 fg + j) = 4 fg + j (j < 4) / 16 + 4 fg + (j - 4): bit 2 of it, which drives the swizzle,
           // is bit 0 of fg for every j
           const unsigned off = (a_base + mw * 64) ^ ((unsigned)(fg & 1) << 6);
-          x[j] = *(const float*)(st + (4 * fg + (j < 4 ? j : 12 + j)) * 1024 + off);
+          xr[mw][j] = *(const float*)(st + (4 * fg + (j < 4 ? j : 12 + j)) * 1024 + off);
         }
       }
-      mx_split8<NP>(x, af[mw]);
     }
-    bf16x8 bfr[NP];
+    bf16x8 bk[T1][NP];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < T1; ++t)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bfr[p] = *(const bf16x8*)(st + b_base + t * 1024 + p * PLANE);
+      for (int p = 0; p < NP; ++p) bk[t][p] = *(const bf16x8*)(st + b_base + t * 1024 + p * PLANE);
+    bf16x8 af[kMxRowTiles][NP];
+    mx_split8<NP>(xr[0], af[0]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mw = 0; mw < kMxRowTiles; ++mw) acc[mw][t] = mx_products<NP>(af[mw], bfr, acc[mw][t]);
+    for (int t = 0; t < T1; ++t) acc[0][t] = mx_products<NP>(af[0], bk[t], acc[0][t]);
+    mx_split8<NP>(xr[1], af[1]);
+    bf16x8 bn[NP];
+    if constexpr (T1 < NT) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bn[p] = *(const bf16x8*)(st + b_base + T1 * 1024 + p * PLANE);
+    }
+    // hipcc hoists the whole second split above the first MFMA otherwise: one MFMA, then two of the split's VALU
+    // instructions (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles), the plane reads of the next column tile
+    // in the last gaps
+#pragma unroll
+    for (int i = 0; i < T1 * (NP == 3 ? 6 : 3); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 2 : 3, 0);  // VALU
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);  // DS read
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < T1; ++t) acc[1][t] = mx_products<NP>(af[1], bk[t], acc[1][t]);
+#pragma unroll
+    for (int t = T1; t < NT; ++t) {
+      bf16x8 bc[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bc[p] = bn[p];
+      if (t + 1 < NT) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bn[p] = *(const bf16x8*)(st + b_base + (t + 1) * 1024 + p * PLANE);
+      }
+#pragma unroll
+      for (int mw = 0; mw < kMxRowTiles; ++mw) acc[mw][t] = mx_products<NP>(af[mw], bc, acc[mw][t]);
     }
     buf = buf + 1 == NSTAGE ? 0 : buf + 1;
   }

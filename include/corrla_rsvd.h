@@ -87,13 +87,16 @@ typedef enum corrla_status {
  * is this block transposed (a stride swap).  Outputs: U m x rank and S replicated on every rank, Vt rank x n_local =
  * this rank's columns of V^T.  opts->omega, when given, is m x l (the short side). */
 #define CORRLA_SHARD_COLS 0x40u
-/* Mixed-precision range finder (f32 row-major inputs, l <= 144; ignored elsewhere): the tall
- * products of power_iter (random_svd.rs:31, 42-51: Y = A Omega, Z = A^T Y, Y = A Z) run on the bf16 matrix units with
- * an f32 accumulator, each f32 operand split on the fly into bf16 pieces whose products are exact in f32:
- *   BF16X6: three pieces (24 bits), six products -- the f32 product to f32 rounding at 16/6 of the exact-f32 MFMA rate;
- *   BF16X3: two pieces (16 bits), three products -- relative error 2^-16 per product, twice that rate again.
- * The thin-Q, the projection B = Q^T A (random_svd.rs:80), the core SVD and U = Q U~ stay in exact f32.  Off by default;
- * the environment variable CORRLA_SKETCH_MIXED=bf16x3|bf16x6 sets it for every call.  Mutually exclusive. */
+/* Mixed-precision tall products (f32 row-major inputs, l <= 144; ignored elsewhere): the
+ * products of the whole matrix with an l-wide factor -- power_iter's Y = A Omega, Z = A^T Y, Y = A Z (random_svd.rs:31,
+ * 42-51) and the projection B = Q^T A (:80; CORRLA_MIXED_PROJECT=0 keeps that one exact) -- run on the bf16 matrix units
+ * with an f32 accumulator, each f32 operand split on the fly into bf16 pieces whose products are exact in f32:
+ *   BF16X6: three pieces (24 bits), six products -- the f32 product to f32 rounding (measured 3.5e-7 relative against
+ *           3.2e-7 for the exact kernel) at 16/6 of the exact-f32 MFMA rate;
+ *   BF16X3: two pieces (16 bits), three products -- 4.5e-6 relative, twice that rate again.
+ * The thin-Qs, the core SVD and U = Q U~ stay in exact f32.  Off by default (the exact f32 path is the reference's
+ * arithmetic); measured effect on the result: profiles/r03_mixed_accuracy.jsonl, DESIGN.md section 3.  The environment
+ * variable CORRLA_SKETCH_MIXED=bf16x3|bf16x6 sets it for every call.  Mutually exclusive. */
 #define CORRLA_SKETCH_BF16X3 0x80u
 #define CORRLA_SKETCH_BF16X6 0x100u
 

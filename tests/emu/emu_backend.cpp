@@ -770,6 +770,11 @@ class EmuDev {
   template <class T>
   void rsqrt_scalar(const double* ss, T* out) { *out = (T)(*ss > 0.0 ? 1.0 / std::sqrt(*ss) : 0.0); }
   template <class T>
+  void inv_norm(const Skinny<T>& y, double* ss, T* inv) {
+    sumsq(y, ss);
+    rsqrt_scalar(ss, inv);
+  }
+  template <class T>
   void scale_inplace(Skinny<T>& y, const T* sc) {
     for (int64_t i = 0; i < y.ld * y.cols_alloc; ++i) y.p[i] *= *sc;
   }

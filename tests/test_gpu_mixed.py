@@ -105,28 +105,52 @@ def _spectrum_matrix(rng, m, n, decay):
     return ((u * (decay ** np.arange(n))) @ v.T).astype(np.float32)
 
 
-@pytest.mark.parametrize("decay", [None, 0.9, 0.7])
+@pytest.mark.parametrize("decay", [None, 0.995, 0.99])
 @pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
-def test_random_svd_with_the_mixed_range_finder_holds_the_f32_gates(ctx, mode, decay):
+def test_random_svd_with_the_mixed_products_holds_the_f32_gates(ctx, mode, decay):
     """Same A, same Omega, GPU with the option on vs the f32 oracle: |d relerr| <= 1e-5 (north star) and
-    max |dS| <= 2e-5 sigma_1 -- the gates of the exact-f32 path (tests/test_gpu_parity.py: _parity)."""
+    max |dS| <= 2e-5 sigma_1 -- the gates of the exact-f32 path (tests/test_gpu_parity.py: _parity) -- on a Gaussian matrix
+    and on the decaying spectra f32 can resolve at this width ((sigma_l / sigma_1)^(2q+1) >= 1e4 eps, the sweep's
+    criterion: 0.995^i and 0.99^i at l = 138, q = 2).  All six tall products run on the split kernels."""
     rng = np.random.default_rng(17)
     m, n, k, q, p = 4096, 1024, 128, 2, 10
     a = _spectrum_matrix(rng, m, n, decay)
     om = rng.standard_normal((n, k + p)).astype(np.float32)
     u, s, vt = ctx.rsvd(a, k, q, p, omega=om, mixed=mode)
-    assert ctx.timings()["n_mixed_products"] == 1 + 2 * q
+    assert ctx.timings()["n_mixed_products"] == 2 + 2 * q
     uo, so, vto = orc.random_svd(a, k, q, p, omega=om)
-    u0, s0, vt0 = ctx.rsvd(a, k, q, p, omega=om)
     ds = float(np.max(np.abs(s.ravel().astype(np.float64) - so.ravel())) / so[0, 0])
-    ds0 = float(np.max(np.abs(s0.ravel().astype(np.float64) - so.ravel())) / so[0, 0])
     dre = abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto))
-    dre0 = abs(orc.relerr(a, u0, s0, vt0) - orc.relerr(a, uo, so, vto))
-    print(f"{mode} decay={decay}: dS/s1 {ds:.2e} (exact path {ds0:.2e}), |d relerr| {dre:.2e} (exact path {dre0:.2e})")
+    print(f"{mode} decay={decay}: dS/s1 {ds:.2e}, |d relerr| {dre:.2e}")
     eps = np.finfo(np.float32).eps
     assert np.max(np.abs(u.T.astype(np.float64) @ u - np.eye(k))) <= 200 * eps * np.sqrt(m)
-    assert dre <= 1e-5
-    assert ds <= (2e-5 if decay is None else 2e-3)     # decaying spectra: the exact path's own tolerance (DESIGN 8)
+    assert np.max(np.abs(vt.astype(np.float64) @ vt.T - np.eye(k))) <= 200 * eps * np.sqrt(n)
+    assert dre <= 1e-5 and ds <= 2e-5
+
+
+@pytest.mark.parametrize("decay", [0.9, 0.7])
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+def test_mixed_products_on_spectra_f32_cannot_resolve(ctx, mode, decay):
+    """0.9^i / 0.7^i at l = 138, q = 2: (sigma_l / sigma_1)^5 is far below eps_f32, so the trailing directions are rounding
+    noise in EVERY f32 run of the reference schedule -- the CPU restatement in f32 and the exact GPU path are both ~1e-2
+    from the f64 oracle (profiles/r03_mixed_accuracy.jsonl).  The split kernels must not be further from it than the exact
+    path by more than a fraction (measured: bf16x6 + 3-10 %, bf16x3 + 10-17 %)."""
+    rng = np.random.default_rng(18)
+    m, n, k, q, p = 4096, 1024, 128, 2, 10
+    a = _spectrum_matrix(rng, m, n, decay)
+    om = rng.standard_normal((n, k + p)).astype(np.float32)
+    ref = orc.random_svd(a.astype(np.float64), k, q, p, omega=om.astype(np.float64))
+
+    def dev(usv):
+        u, s, vt = usv
+        return (float(np.max(np.abs(s.ravel().astype(np.float64) - ref[1].ravel())) / ref[1][0, 0]),
+                abs(orc.relerr(a, u, s, vt) - orc.relerr(a, *ref)))
+
+    ds0, re0 = dev(ctx.rsvd(a, k, q, p, omega=om))
+    ds1, re1 = dev(ctx.rsvd(a, k, q, p, omega=om, mixed=mode))
+    print(f"{mode} decay={decay}: dS {ds1:.2e} (exact path {ds0:.2e}), |d relerr| {re1:.2e} (exact path {re0:.2e})")
+    slack = 1.25 if mode == "bf16x6" else 1.5
+    assert ds1 <= max(2e-5, slack * ds0) and re1 <= max(1e-5, slack * re0)
 
 
 def test_mixed_flag_is_ignored_outside_its_domain(ctx, torch):

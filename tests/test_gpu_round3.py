@@ -201,7 +201,7 @@ def _ref_gradients(x, y, xq, n_nbrs):
     (10000, 8, 12, 500, "offset"),         # a cloud far from the origin: centring keeps the filter's margin small
     (8200, 24, 60, 700, "dups"),           # repeated points: equal distances -> lower index
     (8193, 5, 70, 129, "clustered"),       # tight clusters: many near-ties, query tile tail (129 = 128 + 1)
-    (20000, 64, 65, 64, "gauss"),          # list just beyond one 64-entry half
+    (20000, 64, 67, 64, "gauss"),          # list just beyond one 64-entry half
 ])
 def test_knn2_neighbour_sets_are_exact(ctx, monkeypatch, n, k, n_nbrs, nq, kind):
     """CORRLA_KNN=3 (the default from 8192 points on): gradients equal to those of the exact search -- i.e. the same
