@@ -265,8 +265,8 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
       throw Error(ST_EINVAL, "n_pts and n_nbrs must exceed k + 1 (order 1) / k (k + 3) / 2 (order 2)");
     if (n_nbrs > n_pts) throw Error(ST_EINVAL, "n_nbrs exceeds the number of support points");
     if (n_nbrs > k::kGradMaxNbr) throw Error(ST_EINVAL, "more than 512 neighbours are not supported");
-    if (k::grad_fit_lds_bytes((int)kf, (int)n_nbrs, est_order) > (size_t)160 * 1024)
-      throw Error(ST_EINVAL, "the neighbours and normal equations of one query do not fit in 160 KiB of LDS (order 2 needs k <= 14)");
+    if (k::grad_fit_lds_bytes((int)kf, (int)n_nbrs, est_order, /*m_in_lds=*/false) > (size_t)160 * 1024)
+      throw Error(ST_EINVAL, "the neighbours of one query do not fit in 160 KiB of LDS");
     if (ldg < kf) throw Error(ST_EINVAL, "ldg < k");
     if (n_pts > 0x7fffffff || n_q * n_nbrs > ((int64_t)1 << 40)) throw Error(ST_EINVAL, "point set too large");
     locked_call(c, [&] {
@@ -295,7 +295,9 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     int* status = (int*)dev.alloc_bytes(sizeof(int) * (size_t)n_q);
     hipLaunchKernelGGL(k::grad_transpose_kernel, dim3((unsigned)((n_pts + 255) / 256)), dim3(256), 0, dev.stream, xd, n_pts, kk, xt,
                        ldt);
-    const size_t lds_fit = k::grad_fit_lds_bytes(kk, nn, est_order);
+    // normal equations in LDS when they fit next to the neighbours, else in a per-workgroup slice of global memory
+    const bool m_in_lds = k::grad_fit_lds_bytes(kk, nn, est_order, true) <= (size_t)160 * 1024;
+    const size_t lds_fit = k::grad_fit_lds_bytes(kk, nn, est_order, m_in_lds);
     if (lds_fit > (size_t)160 * 1024) throw Error(ST_EINVAL, "problem does not fit in LDS");
     if (n_q > 0x7fffffff) throw Error(ST_EINVAL, "too many query points for one launch");
     // Both kernels spend ~n_nbrs ln(n_pts / n_nbrs) list insertions per query; the MFMA distance tile only pays off
@@ -329,7 +331,7 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
       ka.ntiles = (n_q + k::kK2Q - 1) / k::kK2Q;
       ka.k = kk;
       ka.n_nbrs = nn;
-      const int64_t wgs = std::min<int64_t>(ka.ntiles, (int64_t)dev.num_cus * std::max(1, env_int("CORRLA_KNN2_WGS_PER_CU", 2)));
+      const int64_t wgs = std::min<int64_t>(ka.ntiles, (int64_t)dev.num_cus * std::max(1, env_int("CORRLA_KNN2_WGS_PER_CU", 1)));
       ka.cand = (int*)dev.alloc_bytes((size_t)wgs * k::kK2Q * k::kK2Cap * sizeof(int));
       ka.list_d = (double*)dev.alloc_bytes((size_t)wgs * k::kK2Q * k::kK2List * sizeof(double));
       ka.list_i = (int*)dev.alloc_bytes((size_t)wgs * k::kK2Q * k::kK2List * sizeof(int));
@@ -368,8 +370,31 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
 #undef CORRLA_KNN_LAUNCH
     }
     const int64_t ldgd = host_ptrs ? kf : ldg;
-    hipLaunchKernelGGL(k::grad_fit_kernel, dim3((unsigned)n_q), dim3(64), lds_fit, dev.stream, xd, yd, kk, qd, n_q, (const int*)nbr,
-                       nn, est_order, out_scale, gd, ldgd, status);
+    // order 1: the MFMA-built normal equations (round 3; CORRLA_FIT=1 keeps the general kernel)
+    if (est_order == 1 && env_int("CORRLA_FIT", 0) != 1) {
+      const size_t lds_lin = k::grad_fit_lin_lds_bytes(kk, nn);
+      const int ntt = (kk + 2 + 15) / 16;
+#define CORRLA_FIT_LAUNCH(N_)                                                                                               \
+  hipLaunchKernelGGL((k::grad_fit_lin_kernel<N_>), dim3((unsigned)n_q), dim3(64), lds_lin, dev.stream, xd, yd, kk, qd, n_q, \
+                     (const int*)nbr, nn, out_scale, gd, ldgd, status)
+      switch (ntt) {
+        case 1: CORRLA_FIT_LAUNCH(1); break;
+        case 2: CORRLA_FIT_LAUNCH(2); break;
+        case 3: CORRLA_FIT_LAUNCH(3); break;
+        case 4: CORRLA_FIT_LAUNCH(4); break;
+        default: CORRLA_FIT_LAUNCH(5); break;
+      }
+#undef CORRLA_FIT_LAUNCH
+    } else if (m_in_lds) {
+      hipLaunchKernelGGL(k::grad_fit_kernel, dim3((unsigned)n_q), dim3(64), lds_fit, dev.stream, xd, yd, kk, qd, n_q, (const int*)nbr,
+                         nn, est_order, out_scale, gd, ldgd, status, (double*)nullptr, (int64_t)0);
+    } else {
+      const int64_t wgs = std::min<int64_t>(n_q, 2 * (int64_t)dev.num_cus);
+      const size_t melems = k::grad_fit_m_elems(kk, est_order);
+      double* mg = (double*)dev.alloc_bytes((size_t)wgs * melems * sizeof(double));
+      hipLaunchKernelGGL(k::grad_fit_kernel, dim3((unsigned)wgs), dim3(64), lds_fit, dev.stream, xd, yd, kk, qd, n_q, (const int*)nbr,
+                         nn, est_order, out_scale, gd, ldgd, status, mg, (int64_t)melems);
+    }
     CORRLA_HIP(hipGetLastError());
     // how many queries needed the ridge / failed: a short reduction on the host (n_q ints)
     std::vector<int> hs((size_t)n_q);

@@ -27,9 +27,9 @@ namespace k {
 
 constexpr int kGradMaxDim = 64;    // features k
 constexpr int kGradMaxNbr = 512;   // neighbours per query (register arrays of the list insertion; LDS is checked per call)
-// design-matrix columns: k + 1 (order 1), k + k (k + 1) / 2 + 1 (order 2); no fixed cap -- the normal equations of a
-// query live in LDS next to its neighbours, so the bound is grad_fit_lds_bytes(k, n_nbrs, order) <= 160 KiB (order 2:
-// k <= 14 with the fewest neighbours the fit needs)
+// design-matrix columns: k + 1 (order 1), k + k (k + 1) / 2 + 1 (order 2); no fixed cap: the neighbours of a query live in
+// LDS (grad_fit_lds_bytes(k, n_nbrs, order, false) <= 160 KiB), its normal equations next to them when they fit (order 2
+// up to k = 14) and in a per-workgroup slice of global memory otherwise (order 2 up to k = 30, where n_nbrs <= 512 binds)
 constexpr int kKnnQueriesPerWave = 4, kKnnWaves = 4, kKnnQueries = kKnnQueriesPerWave * kKnnWaves;
 
 // xt (k x ldt, dimension-major) <- x (n x k, row-major)
@@ -383,23 +383,26 @@ __global__ void point_norms_kernel(const double* __restrict__ xt, int64_t ldt, i
 __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__ x, const double* __restrict__ y, int k,
                                                       const double* __restrict__ xq, int64_t n_q,
                                                       const int* __restrict__ nbr, int n_nbrs, int order, double out_scale,
-                                                      double* g, int64_t ldg, int* status) {
+                                                      double* g, int64_t ldg, int* status, double* m_glob = nullptr,
+                                                      int64_t m_stride = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int P = order == 1 ? k + 1 : k + k * (k + 1) / 2 + 1;  // design columns (the constant is the last one)
   const int LM = (P + 1) | 1;                 // row pitch of M (the right-hand side is column P): ODD, so that the 64 rows
                                               // the lanes of the factorisation walk in step fall in different banks
   double* xn = (double*)smem;                 // [n_nbrs][k] neighbour coordinates minus x0
   double* yn = xn + (size_t)n_nbrs * k;       // [n_nbrs]
-  double* M = yn + n_nbrs;                    // [P][LM] normal equations, lower triangle -> Cholesky factor
-  double* x0 = M + (size_t)P * LM;            // [k]
+  // M: [P][LM] normal equations, lower triangle -> Cholesky factor.  In LDS when it fits next to the neighbours; quadratic
+  // fits of more than 14 features (231 columns at k = 20: 430 KB) keep it in a per-workgroup slice of global memory
+  // (m_glob; L2-resident) and a bounded grid walks the queries -- slower per query, but a fit instead of CORRLA_EINVAL
+  double* M = m_glob ? m_glob + (int64_t)blockIdx.x * m_stride : yn + n_nbrs;
+  double* x0 = yn + n_nbrs + (m_glob ? (size_t)0 : (size_t)P * LM);  // [k]
   double* beta = x0 + k;                      // [P]
   double* dinv = beta + P;                    // [P] 1 / L(i, i)
   int* pa = (int*)(dinv + P);                 // [P] column -> (a, b); b = -1: linear term a; a = -1: constant
   int* pb = pa + P;
   int* flag = pb + P;
   const int lane = threadIdx.x;
-  const int64_t q = blockIdx.x;
-  if (q >= n_q) return;
+  for (int64_t q = blockIdx.x; q < n_q; q += gridDim.x) {  // (one query per workgroup unless M lives in global memory)
   for (int d = lane; d < k; d += 64) x0[d] = xq[q * k + d];
   for (int c = lane; c < P; c += 64) {
     if (c < k) {
@@ -599,11 +602,181 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
     g[q * ldg + m] = out_scale * gm;
   }
   if (lane == 0 && status) status[q] = fl;
+  __syncthreads();  // the LDS images are free for the next query of this workgroup
+  }
 }
-inline size_t grad_fit_lds_bytes(int k, int n_nbrs, int order) {
+// ---- order-1 fits, second generation (round 3) ---------------------------------------------------------------------
+// est_grad_lin (active_subspaces.rs:99-120; linear_fit, stats_corr.rs:146-159) for k <= 64 features: the same normal
+// equations of the design [x - x0, 1] and the same Cholesky solution as grad_fit_kernel, rebuilt around what bounded
+// that kernel at BASELINE config 5 (1e6 queries, k = 64, 80 neighbours: ~0.45 ms per query on ONE wave with 75 KB of LDS,
+// two queries per CU; 1 s of the stage): every one of its phases walked LDS one dependent read at a time.  Here
+//  * the neighbours never touch LDS: lane (c = lane & 15, g = lane >> 4) loads x(nbr[4 s + g], 16 t + c) - x0 straight into
+//    the fragment of v_mfma_f64_16x16x4_f64 it feeds (the A and B fragments of that instruction have the same lane
+//    layout, so ONE register serves both sides of G = D^T D), loads of several neighbour groups in flight;
+//  * the design carries two more columns, the constant and y itself, so the right-hand side D^T y is row k + 1 of the
+//    same product; only the lower-triangle tiles are formed (15 for k = 64), in registers;
+//  * LDS holds the (k + 1) x (k + 3) system only (35 KB: four queries per CU), factorised left-looking with eight
+//    products in flight per lane, solved in the column-oriented form.
+// NTT = 16-column tiles of the design including the constant and y: ceil((k + 2) / 16).
+template <int NTT>
+__global__ __launch_bounds__(64) void grad_fit_lin_kernel(const double* __restrict__ x, const double* __restrict__ y, int k,
+                                                          const double* __restrict__ xq, int64_t n_q,
+                                                          const int* __restrict__ nbr, int n_nbrs, double out_scale, double* g,
+                                                          int64_t ldg, int* status) {
+  typedef double f64x4v __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int P = k + 1;             // unknowns: k slopes and the constant
+  const int LM = (P + 1) | 1;      // odd row pitch; column P holds the right-hand side
+  double* M = (double*)smem;       // [P][LM]
+  double* beta = M + (size_t)P * LM;  // [P]
+  double* dinv = beta + P;            // [P]
+  int* nidx = (int*)(dinv + P);       // [n_nbrs rounded up to 4]
+  const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
+  const int64_t q = blockIdx.x;
+  if (q >= n_q) return;
+  const int n4 = (n_nbrs + 3) & ~3;
+  for (int r = lane; r < n4; r += 64) nidx[r] = r < n_nbrs ? nbr[q * n_nbrs + r] : -1;
+  // this lane's columns of the design: x0 for the coordinate columns
+  double x0c[NTT];
+#pragma unroll
+  for (int t = 0; t < NTT; ++t) x0c[t] = (16 * t + fr < k) ? xq[q * k + 16 * t + fr] : 0.0;
+  __syncthreads();
+  int fl = 0;
+  double ridge = 0.0, dmax = 0.0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    // ---- G = D^T D over the lower-triangle tiles, D = [x - x0, 1, y] (rows = neighbours) ----
+    f64x4v acc[NTT][NTT];
+#pragma unroll
+    for (int a = 0; a < NTT; ++a)
+#pragma unroll
+      for (int b = 0; b < NTT; ++b) acc[a][b] = (f64x4v){0, 0, 0, 0};
+    const int nsteps = n4 >> 2;
+    auto fragment = [&](int s, double (&fv)[NTT]) __attribute__((always_inline)) {
+      const int idx = nidx[4 * s + fg];
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) {
+        const int col = 16 * t + fr;
+        double v = 0.0;
+        if (idx >= 0) {
+          if (col < k) v = x[(int64_t)idx * k + col] - x0c[t];
+          else if (col == k) v = 1.0;
+          else if (col == k + 1) v = y[idx];
+        }
+        fv[t] = v;
+      }
+    };
+    // two neighbour groups in flight: the loads of step s + 1 are issued before the MFMAs of step s
+    double fa[NTT], fb[NTT];
+    fragment(0, fa);
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) fragment(s + 1, fb);
+#pragma unroll
+      for (int a = 0; a < NTT; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fa[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) fa[t] = fb[t];
+    }
+    // D layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 reg
+#pragma unroll
+    for (int a = 0; a < NTT; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int i = 16 * a + fg + 4 * rg, j = 16 * b + fr;
+          const double v = acc[a][b][rg];
+          if (i < P && j <= i) M[i * LM + j] = v + ((i == j) ? ridge : 0.0);
+          if (i == P && j < P) M[j * LM + P] = v;  // row k + 1 of G = D^T y
+        }
+    __syncthreads();
+    if (attempt == 0) {
+      double dm = 0.0;
+      for (int i = lane; i < P; i += 64) dm = fmax(dm, M[i * LM + i]);
+      for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off, 64));
+      dmax = dm;
+    }
+    // ---- Cholesky, left-looking, lane = row (see grad_fit_kernel); eight products in flight per lane ----
+    bool ok = true;
+    for (int j = 0; j < P; ++j) {
+      const double* rj = M + j * LM;
+      auto dot = [&](const double* ri) __attribute__((always_inline)) -> double {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        int p2 = 0;
+        for (; p2 + 7 < j; p2 += 8) {
+          t0 += ri[p2] * rj[p2] + ri[p2 + 4] * rj[p2 + 4];
+          t1 += ri[p2 + 1] * rj[p2 + 1] + ri[p2 + 5] * rj[p2 + 5];
+          t2 += ri[p2 + 2] * rj[p2 + 2] + ri[p2 + 6] * rj[p2 + 6];
+          t3 += ri[p2 + 3] * rj[p2 + 3] + ri[p2 + 7] * rj[p2 + 7];
+        }
+        for (; p2 < j; ++p2) t0 += ri[p2] * rj[p2];
+        return (t0 + t1) + (t2 + t3);
+      };
+      const double sjj = rj[j] - dot(rj);
+      if (!(sjj > 1e-13 * dmax)) {
+        ok = false;
+        break;  // uniform: every lane reads the same row
+      }
+      double rinv = __builtin_amdgcn_rsq(sjj);
+      rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
+      rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
+      const int i0 = j + 1 + lane, i1 = i0 + 64;   // P <= 65: at most two rows per lane
+      double c0 = 0.0, c1 = 0.0;
+      if (i0 < P) c0 = (M[i0 * LM + j] - dot(M + i0 * LM)) * rinv;
+      if (i1 < P) c1 = (M[i1 * LM + j] - dot(M + i1 * LM)) * rinv;
+      __syncthreads();  // every read of row j is done
+      if (i0 < P) M[i0 * LM + j] = c0;
+      if (i1 < P) M[i1 * LM + j] = c1;
+      if (lane == 0) {
+        M[j * LM + j] = sjj * rinv;
+        dinv[j] = rinv;
+      }
+      __syncthreads();
+    }
+    if (ok) break;
+    if (attempt == 1) {
+      fl = 2;  // still singular: zero gradient
+      break;
+    }
+    fl = 1;  // numerically singular design: once more with a 1e-10 relative ridge (the documented deviation)
+    ridge = 1e-10 * dmax;
+    __syncthreads();
+  }
+  if (fl != 2) {
+    for (int r = lane; r < P; r += 64) beta[r] = M[r * LM + P];
+    __syncthreads();
+    for (int i = 0; i < P; ++i) {
+      const double zi = beta[i] * dinv[i];
+      __syncthreads();
+      if (lane == 0) beta[i] = zi;
+      for (int r = i + 1 + lane; r < P; r += 64) beta[r] -= M[r * LM + i] * zi;
+      __syncthreads();
+    }
+    for (int i = P - 1; i >= 0; --i) {
+      const double bi = beta[i] * dinv[i];
+      __syncthreads();
+      if (lane == 0) beta[i] = bi;
+      for (int r = lane; r < i; r += 64) beta[r] -= M[i * LM + r] * bi;
+      __syncthreads();
+    }
+  }
+  for (int m = lane; m < k; m += 64) g[q * ldg + m] = out_scale * (fl != 2 ? beta[m] : 0.0);
+  if (lane == 0 && status) status[q] = fl;
+}
+inline size_t grad_fit_lin_lds_bytes(int k, int n_nbrs) {
+  const int P = k + 1, LM = (P + 1) | 1;
+  return ((size_t)P * LM + 2 * P) * 8 + (size_t)((n_nbrs + 3) & ~3) * 4 + 64;
+}
+
+// m_in_lds = false: the normal equations live in global memory (grad_fit_kernel's m_glob)
+inline size_t grad_fit_lds_bytes(int k, int n_nbrs, int order, bool m_in_lds = true) {
   const int P = order == 1 ? k + 1 : k + k * (k + 1) / 2 + 1;
   const int LM = (P + 1) | 1;
-  return ((size_t)n_nbrs * k + n_nbrs + (size_t)P * LM + k + 2 * P) * 8 + (size_t)(2 * P + 4 + n_nbrs) * 4 + 64;
+  return ((size_t)n_nbrs * k + n_nbrs + (m_in_lds ? (size_t)P * LM : (size_t)0) + k + 2 * P) * 8 + (size_t)(2 * P + 4 + n_nbrs) * 4 + 64;
+}
+inline size_t grad_fit_m_elems(int k, int order) {
+  const int P = order == 1 ? k + 1 : k + k * (k + 1) / 2 + 1;
+  return (size_t)P * (size_t)((P + 1) | 1);
 }
 
 }  // namespace k

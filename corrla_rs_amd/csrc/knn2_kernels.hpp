@@ -20,7 +20,8 @@
 //    candidates at a time, lane = candidate: exact f64 distance from the uncentred rows, a 64-key bitonic sort of
 //    (distance, index), and a two-stage bitonic merge into the query's sorted list of 128 -- ~40 compare-exchange steps
 //    for 64 candidates instead of 64 serial insertions.  A buffer that fills between flush points flushes on the spot.
-//  * 8 scanning waves (128 queries) per workgroup, two or more workgroups per CU, persistent over the query tiles.
+//  * 16 scanning waves (256 queries) per workgroup share every staged chunk, one workgroup per CU, persistent over the
+//    query tiles (with 8 waves the scan sat on the LDS-DMA fill rate: 2 TB staged for 1e6 x 1e6 at ~6.4 TB/s).
 // The neighbour SETS are exact whatever the filter does (a pair the filter drops is farther than the n-th exact
 // distance by more than the bound on the filter's error); the ORDER inside a set is (exact distance, index).
 // Limits: k <= 64, n_nbrs <= 128 (the host falls back to knn_mfma_kernel beyond).
@@ -34,7 +35,8 @@
 namespace corrla {
 namespace k {
 
-constexpr int kK2Waves = 8;             // scanning waves per workgroup
+constexpr int kK2Waves = 16;            // scanning waves per workgroup (they share every staged chunk: the LDS-DMA fill
+                                        // rate, ~25 GB/s per CU, bounded the scan at 8)
 constexpr int kK2Q = 16 * kK2Waves;     // queries per workgroup tile
 constexpr int kK2Cap = 256;             // candidate slots per query between flushes
 constexpr int kK2List = 128;            // list entries per query (n_nbrs <= 128)
@@ -160,7 +162,7 @@ __device__ __forceinline__ void k2_sort(K2Key& a, int lane) {
 }
 
 template <int S>
-__global__ __launch_bounds__(64 * kK2Waves, 2) void knn2_kernel(Knn2Args g) {
+__global__ __launch_bounds__(64 * kK2Waves, 4) void knn2_kernel(Knn2Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STG = k2_stage_bytes(S);
   constexpr int NDMA = S * 8;  // 1 KiB LDS-DMA instructions per chunk (fragments); + one 256-byte one for the norms
@@ -210,15 +212,18 @@ __global__ __launch_bounds__(64 * kK2Waves, 2) void knn2_kernel(Knn2Args g) {
     // D layout: column (point) = lane & 15, row (query) = 4 fg + r
     // (ext-vector registers with constant indices: plain arrays captured by the flush lambdas ended up in scratch)
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    f32x4 qn_r, tau_r;
+    // The filter per pair:  d^2_filter - margin (qn + pn) < tau   <=>   q.p > cq + cp  with
+    //   cq = ((1 - margin) qn - tau) / 2  per query (changes at a flush),  cp = (1 - margin) pn / 2  per point:
+    // one add and one compare per pair, the compare writing the lane mask the slow path needs anyway.
+    // cq = -inf while the list is not full (everything passes), +inf for the padding queries of the last tile
+    // (nothing passes); padding points carry pn = +inf, hence cp = +inf.
+    f32x4 qn_r, cq_r;
     i32x4 cnt_r;
-    unsigned qvalid = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       qn_r[r] = __shfl(qn_mine, 4 * fg + r, 64);
-      tau_r[r] = __builtin_huge_valf();
+      cq_r[r] = (q0 + 4 * fg + r < g.n_q) ? -__builtin_huge_valf() : __builtin_huge_valf();
       cnt_r[r] = 0;
-      if (q0 + 4 * fg + r < g.n_q) qvalid |= 0x1111u << r;  // bit 4 t + r for every t
     }
     // empty lists
     for (int e = lane; e < 16 * kK2List; e += 64) {
@@ -290,14 +295,17 @@ __global__ __launch_bounds__(64 * kK2Waves, 2) void knn2_kernel(Knn2Args g) {
         const int nc = __shfl(mine, 16 * gq, 64);
         if (nc < least || nc == 0) continue;  // uniform
         const double tau = flush_query(qi, nc);
-        // the filter compares in f32: round the threshold UP (never below the exact n-th distance)
+        // the filter compares in f32: round the threshold UP (never below the exact n-th distance); the few ulps the
+        // f32 evaluation of cq loses are part of the margin
         float tf = (float)tau;
         if ((double)tf < tau) tf = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, tf) + 1u);  // tau >= 0: next float up
         if (fg == gq) {
-          if (r == 0) { tau_r[0] = tf; cnt_r[0] = 0; }
-          if (r == 1) { tau_r[1] = tf; cnt_r[1] = 0; }
-          if (r == 2) { tau_r[2] = tf; cnt_r[2] = 0; }
-          if (r == 3) { tau_r[3] = tf; cnt_r[3] = 0; }
+          const float qn_q = r == 0 ? qn_r[0] : (r == 1 ? qn_r[1] : (r == 2 ? qn_r[2] : qn_r[3]));
+          const float cq = tf < __builtin_huge_valf() ? 0.5f * ((1.0f - kK2Margin) * qn_q - tf) : -__builtin_huge_valf();
+          if (r == 0) { cq_r[0] = cq; cnt_r[0] = 0; }
+          if (r == 1) { cq_r[1] = cq; cnt_r[1] = 0; }
+          if (r == 2) { cq_r[2] = cq; cnt_r[2] = 0; }
+          if (r == 3) { cq_r[3] = cq; cnt_r[3] = 0; }
         }
       }
     };
@@ -321,30 +329,30 @@ __global__ __launch_bounds__(64 * kK2Waves, 2) void knn2_kernel(Knn2Args g) {
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, acc[t], 0, 0, 0);
         }
-      unsigned hits = 0;
+      unsigned long long hm[4][4];
+      unsigned long long any = 0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float pnv = *(const float*)(st + k2_chunk_bytes(S) + (16 * t + fr) * 4);  // +inf for padding points
+        const float cp = (0.5f * (1.0f - kK2Margin)) * pnv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float nsum = qn_r[r] + pnv;
-          const float dm = __builtin_fmaf(-2.0f, acc[t][r], nsum);
-          const float lim = __builtin_fmaf(kK2Margin, nsum, tau_r[r]);
-          // the negated comparison lets a NaN through to the exact re-check; padding points (nsum = inf) never pass
-          if (!(dm >= lim) && pnv < __builtin_huge_valf()) hits |= 1u << (4 * t + r);
+          // negated comparison: a NaN goes through to the exact re-check; cq + cp = +inf never passes (inf - inf = NaN
+          // cannot occur: cq = -inf only meets finite cp or cp = +inf of a padding point, which the second test drops)
+          hm[t][r] = __ballot(!(acc[t][r] <= cq_r[r] + cp) && pnv < __builtin_huge_valf());
+          any |= hm[t][r];
         }
       }
-      hits &= qvalid;
-      if (__any(hits != 0)) {
+      if (any != 0) {  // uniform
         const int base = (int)(c * kK2Chunk);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool h = (hits >> (4 * t + r)) & 1u;
-            const unsigned long long m = __ballot(h);
+            const unsigned long long m = hm[t][r];
             if (m == 0) continue;  // uniform
             const unsigned gm = (unsigned)(m >> (16 * fg)) & 0xffffu;  // the 16 points of MY query (4 fg + r)
+            const bool h = (gm >> fr) & 1u;
             const int slot = cnt_r[r] + __popc(gm & ((1u << fr) - 1u));
             if (h && slot < kK2Cap) cand_w[(4 * fg + r) * kK2Cap + slot] = base + 16 * t + fr;
             cnt_r[r] += __popc(gm);

@@ -238,12 +238,8 @@ __device__ void hh_apply_panel(T* P, int RP, int rows, int l, const T* __restric
 //            panel fills the LDS); a wave owns its 16-column tiles for the whole panel: no barriers.
 // tau = 0 (a column that is already reduced) gives a zero column in T: the reflector drops out, as in the unblocked code.
 constexpr int kWyNb = 16;
-#ifndef CORRLA_WY_ONE_WAVE
-#define CORRLA_WY_ONE_WAVE 0
-#endif
-// experiment (off): tree nodes with ONE wave owning a whole block in registers -- no barriers between reflector steps, but
-// the 15 reductions of a step do not overlap as hoped: 142 -> 184 us per node in f32, f64 worse (C1 1.6 -> 2.5 ms)
-constexpr bool kWyOneWave = CORRLA_WY_ONE_WAVE != 0;
+// (A variant in which ONE wave owns a whole 16-column block of a tree node in registers -- no barrier between reflector
+// steps -- measured slower, 142 -> 184 us per node in f32 and worse in f64, and was removed in round 3: CHANGELOG.md.)
 constexpr int kWyPipe = 8;      // k-steps whose operand loads are issued before their MFMAs
 constexpr int kWyRowTiles = 3;  // 16-row tiles of the rank-16 update in flight together
 // down sweep: V streams from global memory (L1 / L2)
@@ -430,73 +426,6 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
     };
     HH_TICK(3)
     // (a) reflectors of the block
-    if constexpr (TRI && kWyOneWave) {
-      // Tree nodes: ONE wave keeps all 16 columns of the block in registers (the block's 16 top rows + the bottom
-      // triangle: NS slices each).  No barrier and no LDS round trip between reflector steps; the 15 dot products of a
-      // step are independent reductions that pipeline.
-      if (wave == 0) {
-        T xb[kWyNb][NS];
-#pragma unroll
-        for (int c = 0; c < kWyNb; ++c) {
-          const T* mc = P + (size_t)min(j0 + c, l - 1) * RP;
-#pragma unroll
-          for (int i = 0; i < NS; ++i) {
-            xb[c][i] = (T)0;
-            if (live(i)) {
-              const int r = rowof(i);
-              const T val = mc[min(r, rows - 1)];
-              xb[c][i] = (c < nbk && r < rows) ? val : (T)0;
-            }
-          }
-        }
-#pragma unroll
-        for (int jj = 0; jj < kWyNb; ++jj) {
-          if (jj < nbk) {
-            const int j = j0 + jj;
-            T* cj = P + (size_t)j * RP;
-            T s2 = (T)0;
-#pragma unroll
-            for (int i = 0; i < NS; ++i)
-              if (live(i)) s2 += rowof(i) > j ? xb[jj][i] * xb[jj][i] : (T)0;
-            const T sigma = hh_wave_sum(s2);
-            const T alpha = hh_readlane(xb[jj][NS - 1], jj);  // row j sits in the top slice, lane jj
-            T tau = (T)0, beta = alpha, scale = (T)0;
-            const T n2 = alpha * alpha + sigma;
-            if (sigma > (T)0 && n2 >= std::numeric_limits<T>::min()) {
-              beta = -copysign(hh_sqrt(n2), alpha);
-              tau = (beta - alpha) * hh_rcp(beta);
-              scale = hh_rcp(alpha - beta);
-            }
-            T vf[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-              const int r = rowof(i);
-              vf[i] = r > j ? xb[jj][i] * scale : (r == j ? (T)1 : (T)0);
-              if (live(i) && r < rows) cj[r] = r > j ? vf[i] : (r == j ? beta : xb[jj][i]);
-            }
-            if (lane == 0) {
-              tau_s[jj] = tau;
-              tau_out[j] = tau;
-            }
-            T d[kWyNb];
-#pragma unroll
-            for (int c = jj + 1; c < kWyNb; ++c) {
-              d[c] = (T)0;
-#pragma unroll
-              for (int i = 0; i < NS; ++i)
-                if (live(i)) d[c] += vf[i] * xb[c][i];
-            }
-#pragma unroll
-            for (int c = jj + 1; c < kWyNb; ++c) d[c] = tau * hh_wave_sum(d[c]);
-#pragma unroll
-            for (int c = jj + 1; c < kWyNb; ++c)
-#pragma unroll
-              for (int i = 0; i < NS; ++i)
-                if (live(i)) xb[c][i] -= d[c] * vf[i];
-          }
-        }
-      }
-    } else {
     T x[NS];
     {
       const T* mc = P + (size_t)min(j0 + wave, l - 1) * RP;
@@ -562,7 +491,6 @@ __device__ void hh_wy_factor_panel(T* P, int RP, int rows, int l, T* tau_out, T*
         for (int i = 0; i < NS; ++i)
           if (live(i)) x[i] -= w * vf[i];
       }
-    }
     }
     if (tid >= nbk && tid < kWyNb) tau_s[tid] = (T)0;
     hh_lds_barrier();

@@ -272,8 +272,9 @@ CORRLA_API corrla_status corrla_fill_normal_dev_f64(corrla_ctx* ctx, double* p, 
  * xq : n_q x k query points (the reference uses the support points themselves);
  * est_order 1: least-squares hyper-plane through the n_nbrs nearest support points of each query (needs n_pts,
  *              n_nbrs > k + 1); 2: full quadratic [x, x_a x_b (a <= b), 1], build_vandermonde (stats_corr.rs:198-207;
- *              needs n_pts, n_nbrs > k (k + 3) / 2).  Limits: k <= 64, n_nbrs <= 512, and one query's neighbours plus
- *              normal equations must fit in 160 KiB of LDS (order 2: k <= 14 with the fewest neighbours the fit needs).
+ *              needs n_pts, n_nbrs > k (k + 3) / 2).  Limits: k <= 64, n_nbrs <= 512 (hence order 2 for k <= 30), and one
+ *              query's neighbours must fit in 160 KiB of LDS; normal equations that do not fit next to them (order 2
+ *              beyond k = 14) live in global memory.
  * g  : out_scale * gradients in the reference's k x n_q column-major layout: n_q rows of k contiguous values, row
  *      stride ldg >= k.  fit_svd (active_subspaces.rs:233-250) passes out_scale = 1 / sqrt(n_q) and hands g to
  *      corrla_rsvd_dev_f64 as the k x n_q matrix (row_stride 1, col_stride ldg).

@@ -247,3 +247,28 @@ def test_knn2_is_the_default_scan_and_handles_few_queries_many_points(ctx, torch
     xs, ys = x.cpu().numpy(), y.cpu().numpy()
     go = aso.create_grad_mat(aso.PolyGradientEstimator(xs, ys, 1, 48), xs[:12])
     assert np.max(np.abs(gm[:, :12].cpu().numpy() - go)) <= 1e-9 * np.abs(go).max()
+
+
+@pytest.mark.parametrize("k,n,n_nbrs", [(20, 3000, 260), (26, 4000, 400)])
+def test_quadratic_fits_beyond_the_lds_limit_of_the_normal_equations(ctx, k, n, n_nbrs):
+    """est_grad_quad (active_subspaces.rs:122-141, stats_corr.rs:198-249) for k = 20 / 26 features: 231 / 378 design columns,
+    normal equations of 430 KB / 1.1 MB per query -- beyond LDS (round 2: CORRLA_EINVAL above k = 14), kept in global memory
+    now.  Same neighbour sets and the same fitted quadratics as the oracle."""
+    from oracle import active_ss_oracle as aso
+    rng = np.random.default_rng(k)
+    x = rng.standard_normal((n, k)) + 0.5
+    qm = rng.standard_normal((k, k)) * 0.1
+    qm = qm + qm.T
+    b = rng.standard_normal(k)
+    y = 0.5 * np.einsum("ni,ij,nj->n", x, qm, x) + x @ b + 3.0 + 1e-3 * np.sin(x @ b)
+    nq = 24
+    g, nreg = ctx.grad_mat(x, y, 2, n_nbrs, x[:nq])
+    assert g.shape == (k, nq) and nreg == 0
+    est = aso.PolyGradientEstimator(x, y, 2, n_nbrs)
+    est.exact_quad_gradient = True       # the same fitted quadratics differentiated exactly
+    go = aso.create_grad_mat(est, x[:nq])
+    assert np.max(np.abs(g - go)) <= 1e-7 * np.abs(go).max()
+    # an exact quadratic with an offset is recovered exactly
+    y2 = 0.5 * np.einsum("ni,ij,nj->n", x, qm, x) + x @ b + 3.0
+    g2, _ = ctx.grad_mat(x, y2, 2, n_nbrs, x[:nq])
+    assert np.max(np.abs(g2 - (x[:nq] @ qm + b).T)) <= 1e-6 * np.abs(g2).max()
