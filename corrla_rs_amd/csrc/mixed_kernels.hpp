@@ -20,7 +20,7 @@
 // Workgroup = 8 MFMA waves (two per SIMD: one's LDS reads and split arithmetic run under the other's MFMAs) + 4
 // loader waves; it owns 256 outer indices (wave w: 32 of them = 2 MFMA row tiles) and all NT <= 9 column tiles, so R is
 // read from HBM once.  Reduction tile: 32 deep = ONE 16x16x32 step per (row tile, column tile, product); LDS stage =
-// 32 KiB of R + NP * NT * 1 KiB of X planes, ring of 2 (NP = 3) or 3 (NP = 2) stages.
+// 32 KiB of R (ring of 3: two tiles of HBM latency in flight) + NP * NT * 1 KiB of X planes (ring of 2, L2-served).
 //
 // MFMA operand maps (cdna_hip_programming.md section 3): A[row = lane & 15][k = 8 (lane >> 4) + j],
 // B[k = 8 (lane >> 4) + j][col = lane & 15], j = 0..7;  D: col = lane & 15, row = 4 (lane >> 4) + reg.  The big operand
@@ -48,10 +48,13 @@ constexpr int kMxRowTiles = 2;               // 16-wide outer tiles per MFMA wav
 constexpr int kMxOuter = kMxWaves * kMxRowTiles * 16;  // 256 outer indices per workgroup
 constexpr int kMxKT = 32;                    // reduction indices per tile (one 16x16x32 step)
 constexpr int kMxBigBytes = kMxOuter * kMxKT * 4;       // 32 KiB
-__host__ __device__ constexpr int mx_plane_bytes(int nt) { return nt * 16 * kMxKT * 2; }  // one plane of one stage
-__host__ __device__ constexpr int mx_stage_bytes(int nt, int np) { return kMxBigBytes + np * mx_plane_bytes(nt); }
-__host__ __device__ constexpr int mx_stages(int nt, int np) { return 3 * mx_stage_bytes(nt, np) + 1024 <= 160 * 1024 ? 3 : 2; }
-__host__ __device__ constexpr int mx_lds_bytes(int nt, int np) { return mx_stages(nt, np) * mx_stage_bytes(nt, np) + 1024; }
+__host__ __device__ constexpr int mx_plane_bytes(int nt) { return nt * 16 * kMxKT * 2; }  // one plane of one tile
+// Two LDS rings: the big operand comes from HBM and is prefetched TWO tiles ahead (3 slots of 32 KiB); the planes of the
+// skinny operand are re-read by every workgroup, i.e. served by L2, and run one tile ahead (2 slots).  (Round 3's first
+// version had one ring of whole tiles: only 2 fit for three planes, and the DMA cost 30 % on top of the DMA-free time.)
+constexpr int kMxASlots = 3, kMxBSlots = 2;
+__host__ __device__ constexpr int mx_bslot_bytes(int nt, int np) { return np * mx_plane_bytes(nt); }
+__host__ __device__ constexpr int mx_lds_bytes(int nt, int np) { return kMxASlots * kMxBigBytes + kMxBSlots * mx_bslot_bytes(nt, np) + 1024; }
 
 // reduction index (inside a 32-deep tile) that position p = 8 g + j of a plane row / MFMA fragment holds
 __host__ __device__ constexpr int mx_kmap(int p) { return (p & 4) ? 16 + 4 * (p >> 3) + (p & 3) : 4 * (p >> 3) + (p & 3); }
@@ -203,9 +206,10 @@ __host__ __device__ constexpr int mx_tn_swz(int kr) { return ((kr >> 2) & 1) << 
 
 template <int NT, int NP, bool TN>
 __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_kernel(MxArgs g) {
-  constexpr int STAGE = mx_stage_bytes(NT, NP);
-  constexpr int NSTAGE = mx_stages(NT, NP);
   constexpr int PLANE = mx_plane_bytes(NT);
+  constexpr int BSLOT = mx_bslot_bytes(NT, NP);
+  constexpr int BRING = kMxASlots * kMxBigBytes;  // byte offset of the plane ring
+  static_assert(mx_lds_bytes(9, 3) <= 160 * 1024, "LDS budget");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (g.run_if && *g.run_if == 0) return;  // uniform over the grid
   const int lane = threadIdx.x & 63;
@@ -216,63 +220,71 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
   const int nk = t_end - t_begin;
 
   if (wave >= kMxWaves) {
-    // ---- loader waves: tile kt -> buffer buf.  Chunks of 1 KiB dealt round-robin; every loader issues the same number
-    // of DMA instructions per tile (the short ones add a dummy into the scratch KiB), so the counted wait is uniform.
+    // ---- loader waves.  Chunks of 1 KiB dealt round-robin; every loader issues the same number of DMA instructions per
+    // tile and ring (the short ones add a dummy into the scratch KiB), so the counted wait is uniform.
     __builtin_amdgcn_s_setprio(3);
     const int lw = wave - kMxWaves;
-    constexpr int NBIG = kMxBigBytes / 1024;          // 32
-    constexpr int NSK = NP * NT;                      // plane chunks
-    constexpr int NCH = NBIG + NSK;
-    constexpr int DPL = (NCH + kMxLoaders - 1) / kMxLoaders;  // DMA instructions per loader and tile
-    char* scratch = smem + NSTAGE * STAGE;
-    auto stage_tile = [&](int buf, int kt) {
-      char* st = smem + buf * STAGE;
+    constexpr int NBIG = kMxBigBytes / 1024;                        // 32 chunks of the big operand per tile
+    constexpr int DA = NBIG / kMxLoaders;                           // 8 per loader
+    constexpr int NSK = NP * NT;                                    // plane chunks per tile
+    constexpr int DB = (NSK + kMxLoaders - 1) / kMxLoaders;         // per loader (padded)
+    char* scratch = smem + BRING + kMxBSlots * BSLOT;
+    auto stage_big = [&](int slot, int kt) {
+      char* st = smem + slot * kMxBigBytes;
       const int64_t k0 = (int64_t)kt * kMxKT;
 #pragma unroll
-      for (int i = 0; i < DPL; ++i) {
+      for (int i = 0; i < DA; ++i) {
         const int c = lw + kMxLoaders * i;
-        if (c < NBIG) {
-          if ((g.debug_flags & 4) && kt > t_begin + NSTAGE) {
-            glds16(g.zero, scratch);
-            continue;
-          }
-          const float* src;
-          if constexpr (!TN) {
-            const int row = 8 * c + (lane >> 3);
-            const int ls = (lane & 7) ^ mx_big_swz(row);
-            const int64_t grow = outer_first + row, kk = k0 + 4 * ls;
-            src = (grow < g.r_rows && kk < g.r_cols_readable) ? g.r + grow * g.r_ld + kk : g.zero;
-          } else {
-            const int kr = c;  // reduction row of the tile
-            const int ls = lane ^ mx_tn_swz(kr);
-            const int64_t grow = k0 + kr, oc = outer_first + 4 * ls;
-            src = (grow < g.r_rows && oc < g.r_cols_readable) ? g.r + grow * g.r_ld + oc : g.zero;
-          }
-          glds16(src, st + c * 1024);
-        } else if (c < NCH) {
-          if ((g.debug_flags & 2) && kt > t_begin + NSTAGE) {
-            glds16(g.zero, scratch);
-            continue;
-          }
-          const int cc = c - NBIG;
-          const int p = cc / NT, ct = cc - p * NT;
-          const int row = 16 * ct + (lane >> 2);
-          const int ls = (lane & 3) ^ mx_plane_swz(row);
-          glds16(g.planes + p * g.plane_stride + (int64_t)row * g.x_ld + k0 + 8 * ls, st + kMxBigBytes + p * PLANE + ct * 1024);
-        } else {
-          glds16(g.zero, scratch);  // keeps the per-tile DMA count uniform over the loaders
+        if ((g.debug_flags & 4) && kt > t_begin + 2) {
+          glds16(g.zero, scratch);
+          continue;
         }
+        const float* src;
+        if constexpr (!TN) {
+          const int row = 8 * c + (lane >> 3);
+          const int ls = (lane & 7) ^ mx_big_swz(row);
+          const int64_t grow = outer_first + row, kk = k0 + 4 * ls;
+          src = (grow < g.r_rows && kk < g.r_cols_readable) ? g.r + grow * g.r_ld + kk : g.zero;
+        } else {
+          const int kr = c;  // reduction row of the tile
+          const int ls = lane ^ mx_tn_swz(kr);
+          const int64_t grow = k0 + kr, oc = outer_first + 4 * ls;
+          src = (grow < g.r_rows && oc < g.r_cols_readable) ? g.r + grow * g.r_ld + oc : g.zero;
+        }
+        glds16(src, st + c * 1024);
       }
     };
-    for (int t = 0; t < NSTAGE - 1 && t < nk; ++t) stage_tile(t % NSTAGE, t_begin + t);
+    auto stage_planes = [&](int slot, int kt) {
+      char* st = smem + BRING + slot * BSLOT;
+      const int64_t k0 = (int64_t)kt * kMxKT;
+#pragma unroll
+      for (int i = 0; i < DB; ++i) {
+        const int cc = lw + kMxLoaders * i;
+        if (cc >= NSK || ((g.debug_flags & 2) && kt > t_begin + 2)) {
+          glds16(g.zero, scratch);  // keeps the per-tile DMA count uniform over the loaders
+          continue;
+        }
+        const int p = cc / NT, ct = cc - p * NT;
+        const int row = 16 * ct + (lane >> 2);
+        const int ls = (lane & 3) ^ mx_plane_swz(row);
+        glds16(g.planes + p * g.plane_stride + (int64_t)row * g.x_ld + k0 + 8 * ls, st + p * PLANE + ct * 1024);
+      }
+    };
+    // issue order (vmcnt retires in order):  B(0) A(0) A(1) | then per tile i, after its barrier:  B(i+1) A(i+2).
+    // Before barrier i the planes and the big tile of i must have landed; the ONE younger group, A(i+1), may stay in flight.
+    if (nk > 0) {
+      stage_planes(0, t_begin);
+      stage_big(0, t_begin);
+      if (nk > 1) stage_big(1, t_begin + 1);
+    }
     for (int i = 0; i < nk; ++i) {
-      // tile i must have landed; the (NSTAGE - 2) younger tiles may stay in flight (vmcnt counts in issue order)
-      if (NSTAGE > 2 && i + NSTAGE - 2 < nk)
-        wait_vmcnt<(NSTAGE - 2) * DPL>();
+      if (i + 1 < nk)
+        wait_vmcnt<DA>();
       else
         wait_vmcnt<0>();
-      wg_barrier();  // tile i visible to the MFMA waves; they are done reading buffer (i - 1) % NSTAGE
-      if (i + NSTAGE - 1 < nk) stage_tile((i + NSTAGE - 1) % NSTAGE, t_begin + i + NSTAGE - 1);
+      wg_barrier();  // tile i visible to the MFMA waves; they are done with tile i - 1 (its slots are free)
+      if (i + 1 < nk) stage_planes((i + 1) % kMxBSlots, t_begin + i + 1);
+      if (i + 2 < nk) stage_big((i + 2) % kMxASlots, t_begin + i + 2);
     }
     return;
   }
@@ -290,11 +302,12 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
   //   tn: outer column oc = 32 wave + 16 mw + fr; the per-row swizzle is applied below
   const unsigned a_base = !TN ? (unsigned)((32 * wave + fr) * 128 + ((fg ^ mx_big_swz(fr)) << 4))
                               : (unsigned)((((32 * wave + fr) >> 2) << 4) + ((fr & 3) << 2));
-  const unsigned b_base = (unsigned)(kMxBigBytes + fr * 64 + ((fg ^ mx_plane_swz(fr)) << 4));
-  int buf = 0;
+  const unsigned b_base = (unsigned)(fr * 64 + ((fg ^ mx_plane_swz(fr)) << 4));  // inside a slot of the plane ring
+  int abuf = 0, bbuf = 0;
   for (int i = 0; i < nk; ++i) {
     wg_barrier();  // matches the loaders' barrier: tile i is in LDS
-    const char* st = smem + buf * STAGE;
+    const char* st = smem + abuf * kMxBigBytes;            // big-operand slot
+    const char* sb = smem + BRING + bbuf * BSLOT;          // plane slot
     // Schedule of one tile (everything below is one basic block; round 3 measured the first version -- both splits, then
     // nine groups of [3 LDS reads, wait, 12 MFMAs] -- at 55 % matrix-pipe occupancy with NO DMA at all: the two waves of a
     // SIMD run in step, so both split, then both wait on LDS):
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
 #pragma unroll
     for (int t = 0; t < T1; ++t)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bk[t][p] = *(const bf16x8*)(st + b_base + t * 1024 + p * PLANE);
+      for (int p = 0; p < NP; ++p) bk[t][p] = *(const bf16x8*)(sb + b_base + t * 1024 + p * PLANE);
     bf16x8 af[kMxRowTiles][NP];
     mx_split8<NP>(xr[0], af[0]);
     __builtin_amdgcn_sched_barrier(0);
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
     bf16x8 bn[NP];
     if constexpr (T1 < NT) {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bn[p] = *(const bf16x8*)(st + b_base + T1 * 1024 + p * PLANE);
+      for (int p = 0; p < NP; ++p) bn[p] = *(const bf16x8*)(sb + b_base + T1 * 1024 + p * PLANE);
     }
     // hipcc hoists the whole second split above the first MFMA otherwise: one MFMA, then two of the split's VALU
     // instructions (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles), the plane reads of the next column tile
@@ -359,12 +372,13 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
       for (int p = 0; p < NP; ++p) bc[p] = bn[p];
       if (t + 1 < NT) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) bn[p] = *(const bf16x8*)(st + b_base + (t + 1) * 1024 + p * PLANE);
+        for (int p = 0; p < NP; ++p) bn[p] = *(const bf16x8*)(sb + b_base + (t + 1) * 1024 + p * PLANE);
       }
 #pragma unroll
       for (int mw = 0; mw < kMxRowTiles; ++mw) acc[mw][t] = mx_products<NP>(af[mw], bc, acc[mw][t]);
     }
-    buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+    abuf = abuf + 1 == kMxASlots ? 0 : abuf + 1;
+    bbuf = bbuf + 1 == kMxBSlots ? 0 : bbuf + 1;
   }
   const int64_t limit = TN ? g.r_cols : g.r_rows;
 #pragma unroll

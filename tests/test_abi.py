@@ -133,3 +133,41 @@ def test_product_sources_do_not_reference_oracle_or_emulation():
                 txt = open(os.path.join(base, f)).read()
                 assert "rsvd_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
                 assert "emu_backend" not in txt and "libcorrla_emu" not in txt or f == "build.py", f
+
+
+def test_every_kernel_the_host_code_launches_exists_in_the_device_code_object():
+    """hipcc compiles the host and the gfx950 halves of corrla_rsvd.hip separately; the HIP runtime resolves a kernel by
+    NAME in the embedded code object the first time the host touches it and aborts the process when the name is missing
+    (seen once in round 3: `Cannot find Symbol with name: ...grad_fit_kernel...` killed every GPU test of a batch).  Every
+    `__device_stub__` in the host symbol table must have its kernel and kernel descriptor in the device ELF."""
+    import re
+    import subprocess
+    from corrla_rs_amd import build as B
+    lib = B.build_product()
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not available")
+    host = subprocess.run([readelf, "-s", "--wide", lib], capture_output=True, text=True, check=True).stdout
+    stubs = set()
+    for sym in re.findall(r"\s(_Z\S*__device_stub__\S*)", host):
+        # <len>__device_stub__<name>  ->  <len - 15><name>
+        m = re.search(r"(\d+)__device_stub__", sym)
+        n = int(m.group(1))
+        ident = sym[m.end(1): m.end(1) + n]
+        name = ident[len("__device_stub__"):]
+        stubs.add(sym[: m.start(1)] + str(len(name)) + name + sym[m.end(1) + n:])
+    assert len(stubs) > 100, "host symbol table stripped? (%d stubs)" % len(stubs)
+    data = open(lib, "rb").read()
+    dev = ""
+    for mm in re.finditer(b"\x7fELF", data):
+        i = mm.start()
+        if data[i + 18: i + 20] == b"\xe0\x00":      # e_machine = EM_AMDGPU
+            tmp = os.path.join(os.path.dirname(lib), "_device_code_object.tmp")
+            with open(tmp, "wb") as f:
+                f.write(data[i:])
+            dev += subprocess.run([readelf, "-s", "--wide", tmp], capture_output=True, text=True).stdout
+            os.remove(tmp)
+    assert dev, "no gfx950 code object found in the library"
+    have = set(re.findall(r"\s(_Z\S+)", dev))
+    missing = sorted(s for s in stubs if s not in have or (s + ".kd") not in have)
+    assert not missing, "kernels without device code: %s" % missing[:5]
