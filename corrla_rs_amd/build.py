@@ -41,14 +41,29 @@ def build_product(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libcorrla_rsvd.so")
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma",  # host-side l x l factorizations (small_linalg.hpp)
-           "-I" + os.path.join(ROOT, "include"), os.path.join(CSRC, "corrla_rsvd.hip"),
-           "-o", LIB_PATH, "-L" + os.path.join(ROCM, "lib"), "-lrccl",
-           "-Wl,-rpath," + os.path.join(ROCM, "lib")]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # hipcc parses the translation unit twice (device pass, then host pass, about a minute apart): a header edited in between
+    # gives a library whose host code launches kernels its device code object does not hold (seen twice in round 3 as
+    # "Cannot find Symbol" at the first launch on the GPU box).  So: compile a private copy of the sources, and put the
+    # result in place with one rename -- a snapshot of the tree taken during a build sees the old library or the new one.
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="corrla_build_") as tmp:
+        csrc = os.path.join(tmp, "corrla_rs_amd", "csrc")  # same relative layout: the sources include "../../include/..."
+        shutil.copytree(CSRC, csrc)
+        shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+        out_tmp = os.path.join(LIB_DIR, ".libcorrla_rsvd.so.%d" % os.getpid())
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+               "-Xarch_host", "-mavx2", "-Xarch_host", "-mfma",  # host-side l x l factorizations (small_linalg.hpp)
+               "-I" + os.path.join(tmp, "include"), os.path.join(csrc, "corrla_rsvd.hip"),
+               "-o", out_tmp, "-L" + os.path.join(ROCM, "lib"), "-lrccl",
+               "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(out_tmp, LIB_PATH)
+        finally:
+            if os.path.exists(out_tmp):
+                os.remove(out_tmp)
     return LIB_PATH
 
 

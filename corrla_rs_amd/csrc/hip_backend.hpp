@@ -117,6 +117,9 @@ class HipDev {
     persist_max_tiles_ = env_int("CORRLA_GEMM_PERSIST_TILES", 16);  // 0: one workgroup per outer tile everywhere
     gemm_debug_flags_ = env_int("CORRLA_GEMM_DEBUG", 0);  // timing-only ablations, results are wrong
     if (const char* e = std::getenv("CORRLA_MIXED_MIN_WORK")) mixed_min_work_ = std::atof(e);
+    gemm_wide_mode_ = env_int("CORRLA_GEMM_WIDE", gemm_wide_mode_);
+    f64_mfma_waves_ = env_int("CORRLA_F64_WAVES", f64_mfma_waves_);
+    gemm_wide_max_red_ = env_int("CORRLA_GEMM_WIDE_MAX_RED", (int)gemm_wide_max_red_);
   }
   ~HipDev() {
     (void)hipSetDevice(device);
@@ -299,11 +302,13 @@ class HipDev {
   template <class T>
   void gemm_nn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale_dev) {
     if (x.rows != r.cols) throw Error(ST_EINVAL, "gemm_nn: inner dimensions differ");
+    if (wide_exact_wanted<T>(false, r, x, out)) return gemm_mixed<T>(false, r, x, out, scale_dev, 0);
     launch_gemm<T>(false, r, x, out, scale_dev, r.rows, r.cols);
   }
   template <class T>
   void gemm_tn(const Big<T>& r, const Skinny<T>& x, Skinny<T>& out, const T* scale_dev) {
     if (x.rows != r.rows) throw Error(ST_EINVAL, "gemm_tn: inner dimensions differ");
+    if (wide_exact_wanted<T>(true, r, x, out)) return gemm_mixed<T>(true, r, x, out, scale_dev, 0);
     launch_gemm<T>(true, r, x, out, scale_dev, r.cols, r.rows);
   }
 
@@ -323,6 +328,20 @@ class HipDev {
       if ((const void*)r.p == (const void*)x.p) return false;  // Gram products stay exact
       // (CORRLA_MIXED_MIN_WORK: tests drive small shapes through the kernels)
       return outer_n >= 1 && red_n >= 1 && (double)outer_n * (double)red_n >= (double)mixed_min_work_;
+    }
+  }
+  // np = 0 runs the same 8-wave / 256-outer-index skeleton with EXACT f32 MFMAs (mixed_kernels.hpp): the skinny operand is
+  // restaged half as often as in the 4-wave kernels of gemm_kernels.hpp, which is what bounds the short-reduction
+  // products (CORRLA_GEMM_WIDE: 0 = never, 1 = whenever the operands fit, 2 = by shape; see wide_exact_wanted).
+  template <class T>
+  bool wide_exact_wanted(bool tn, const Big<T>& r, const Skinny<T>& x, const Skinny<T>& out) const {
+    if constexpr (!std::is_same<T, float>::value) {
+      return false;
+    } else {
+      if (gemm_wide_mode_ == 0 || !mixed_fits<float>(tn, r, x, out)) return false;
+      if (gemm_wide_mode_ == 1) return true;
+      const int64_t red_n = tn ? r.rows : r.cols;
+      return red_n <= gemm_wide_max_red_;
     }
   }
   template <int NT, int NP, bool TN>
@@ -357,7 +376,7 @@ class HipDev {
       throw Error(ST_EINVAL, "internal: the bf16-split products are f32 only");
   }
   void gemm_mixed_f32(bool tn, const Big<float>& r, const Skinny<float>& x, Skinny<float>& out, const float* scale_dev, int np) {
-    if (np != 2 && np != 3) throw Error(ST_EINVAL, "internal: bf16 split takes 2 or 3 planes");
+    if (np != 0 && np != 2 && np != 3) throw Error(ST_EINVAL, "internal: bf16 split takes 2 or 3 planes (0 = exact f32)");
     if (!mixed_fits<float>(tn, r, x, out)) throw Error(ST_EINVAL, "internal: operands outside the bf16-split kernels' domain");
     const int64_t outer_n = tn ? r.cols : r.rows, red_n = tn ? r.rows : r.cols;
     const ColBlocking cb = col_blocking(x.cols);
@@ -365,8 +384,8 @@ class HipDev {
       throw Error(ST_EINVAL, "internal: skinny column padding too small for the column blocking");
     // the skinny operand in np bf16 planes, reduction index in MFMA fragment order
     const int64_t plane_stride = x.ld * cb.cols_alloc;
-    __bf16* planes = (__bf16*)alloc_bytes((size_t)np * (size_t)plane_stride * 2);
-    {
+    __bf16* planes = np ? (__bf16*)alloc_bytes((size_t)np * (size_t)plane_stride * 2) : (__bf16*)x.p;  // exact: X as it is
+    if (np) {
       const int64_t slots = plane_stride / 8;
       const dim3 sg((unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (slots + 255) / 256)));
       if (np == 3)
@@ -410,7 +429,9 @@ class HipDev {
     a.debug_flags = gemm_debug_flags_;
     const dim3 grid((unsigned)outer_tiles, 1, (unsigned)nsplit);
     check_grid(grid);
-    if (np == 3) {
+    if (np == 0) {
+      if (tn) mixed_launch_nt<0, true>(cb.nt, grid, a); else mixed_launch_nt<0, false>(cb.nt, grid, a);
+    } else if (np == 3) {
       if (tn) mixed_launch_nt<3, true>(cb.nt, grid, a); else mixed_launch_nt<3, false>(cb.nt, grid, a);
     } else {
       if (tn) mixed_launch_nt<2, true>(cb.nt, grid, a); else mixed_launch_nt<2, false>(cb.nt, grid, a);
@@ -1516,6 +1537,9 @@ class HipDev {
   int jmc_extra_sweeps_ = 0, jmc_sweeps_hint_ = 0;
   bool jmc_force_v_ = false;
   int64_t tall_min_rows_ = 65536;
+  int f64_mfma_waves_ = 8;
+  int gemm_wide_mode_ = 0;
+  int64_t gemm_wide_max_red_ = 2048;
   double mixed_min_work_ = 16777216.0;  // outer x reduction elements below which a product keeps the exact kernels
 
   static void check_grid(const dim3& g) {
@@ -1531,6 +1555,10 @@ class HipDev {
     CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_tn_kernel<T, 2, NT>, attr, k::gemm_lds_bytes(2, NT)));
     if constexpr (NT <= 8)
       CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_nn_kernel<T, 2, NT, true>, attr, 3 * k::big_tile_bytes(2)));
+    if constexpr (std::is_same<T, double>::value) {  // two MFMA waves per SIMD on the MW = 2 tile (launch_mw)
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_nn_kernel<T, 1, NT, false, 8>, attr, k::gemm_lds_bytes(2, NT)));
+      CORRLA_HIP(hipFuncSetAttribute((const void*)k::gemm_tn_kernel<T, 1, NT, 8>, attr, k::gemm_lds_bytes(2, NT)));
+    }
   }
   template <class T>
   static void set_jacobi_attrs() {
@@ -1579,18 +1607,19 @@ class HipDev {
     *nsplit_out = std::min(ns, 65535);
   }
 
-  template <class T, int MW, int NT>
+  template <class T, int MW, int NT, int NW = 4>
   void launch_one(bool tn, dim3 grid, const k::GemmArgs<T>& a) {
+    constexpr int GW = MW * NW / 4;  // row tiles per SIMD: the tile geometry (hip_kernels.hpp: gemm_nn_kernel)
     // the kernels only touch ring buffers [0, min(tiles per workgroup, stages)): a short reduction (the l-deep
     // products Y * R^-1 and U = Q * U~ have 2-3 tiles) asks for less LDS, so several workgroups share a CU and one's
     // load latency hides behind another's MFMAs and stores
     const int64_t per_wg = (int64_t)std::max(1, a.tiles_per_split) * ((a.outer_blocks + (int64_t)grid.x - 1) / grid.x);
-    const int lds = (int)std::min<int64_t>(k::gemm_stages(MW, NT), per_wg) * k::stage_bytes(MW, NT);
-    const dim3 block(64 * (4 + k::kLoaders));  // 4 MFMA waves + loader wave(s)
+    const int lds = (int)std::min<int64_t>(k::gemm_stages(GW, NT), per_wg) * k::stage_bytes(GW, NT);
+    const dim3 block(64 * (NW + k::kLoaders));  // MFMA waves + loader waves
     if (tn)
-      hipLaunchKernelGGL((k::gemm_tn_kernel<T, MW, NT>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((k::gemm_tn_kernel<T, MW, NT, NW>), grid, block, lds, stream, a);
     else
-      hipLaunchKernelGGL((k::gemm_nn_kernel<T, MW, NT>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((k::gemm_nn_kernel<T, MW, NT, false, NW>), grid, block, lds, stream, a);
   }
   template <class T>
   void launch_nt(bool tn, int mw, int nt, dim3 grid, const k::GemmArgs<T>& a) {
@@ -1614,10 +1643,16 @@ class HipDev {
   }
   template <class T, int NT>
   void launch_mw(bool tn, int mw, dim3 grid, const k::GemmArgs<T>& a) {
-    if (mw == 2)
+    if (mw == 2) {
+      // f64: the same 128-index tile with EIGHT MFMA waves of one row tile each -- two waves per SIMD keep the f64 matrix
+      // pipe busier than one can (77.8 vs 60.5 TF register-only); CORRLA_F64_WAVES=4 keeps round 2's shape
+      if constexpr (std::is_same<T, double>::value) {
+        if (f64_mfma_waves_ == 8) return launch_one<T, 1, NT, 8>(tn, grid, a);
+      }
       launch_one<T, 2, NT>(tn, grid, a);
-    else
+    } else {
       launch_one<T, 1, NT>(tn, grid, a);
+    }
   }
 
   // ---- tall_kernels.hpp: Y M and Y^T Y of a very tall sketch with l <= 96 (f32) / 64 (f64) ----

@@ -269,41 +269,46 @@ __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename 
 // ALIAS (Gram matrices, G = Y^T Y: the big operand's memory IS the skinny operand's, and the single outer tile
 // holds every column): the skinny fragments are read from the big tile's LDS image -- same rows, same swizzle -- so
 // the operand is staged ONCE per tile instead of twice (the Gram of a 10^7 x 80 sketch read Y twice: 6.4 GB).
-template <class T, int MW, int NT, bool ALIAS = false>
-__global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T> g) {
+// NW = MFMA waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD, each with MW row tiles; the tile geometry is that of
+// GW = MW * NW / 4 row tiles per SIMD).  Two f64 MFMA waves per SIMD reach 77.8 TF where one reaches 60.5
+// (tools/microbench/mfma_chain.hip): the f64 products run <double, 1, NT, false, 8> on the 128-row tile of <double, 2, NT>.
+template <class T, int MW, int NT, bool ALIAS = false, int NW = 4>
+__global__ __launch_bounds__(64 * (NW + kLoaders)) void gemm_nn_kernel(GemmArgs<T> g) {
+  constexpr int GW = MW * NW / 4;
+  static_assert(NW == 4 || (NW == 8 && !ALIAS), "4 or 8 MFMA waves");
   typedef typename MT<T>::acc_t acc_t;
   typedef typename MT<T>::vec_t vec_t;
   constexpr int VEC = MT<T>::VEC;
   constexpr int KT = MT<T>::KT;
-  constexpr int STAGE = ALIAS ? big_tile_bytes(MW) : stage_bytes(MW, NT);
-  constexpr int BIG = big_tile_bytes(MW);
-  static_assert(!ALIAS || 16 * NT <= 64 * MW, "alias: the outer tile must hold every column");
+  constexpr int STAGE = ALIAS ? big_tile_bytes(GW) : stage_bytes(GW, NT);
+  constexpr int BIG = big_tile_bytes(GW);
+  static_assert(!ALIAS || 16 * NT <= 64 * GW, "alias: the outer tile must hold every column");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (g.run_if && *g.run_if == 0) return;  // uniform over the grid
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row_first = (int64_t)blockIdx.x * outer_tile(MW);
+  const int64_t row_first = (int64_t)blockIdx.x * outer_tile(GW);
   const int64_t col0 = g.col_base + (int64_t)blockIdx.y * (NT * 16);
   const int t_begin = blockIdx.z * g.tiles_per_split;
   const int t_end = min(t_begin + g.tiles_per_split, g.tiles_total);
   const int nk = t_end - t_begin;
   // outer tiles of this workgroup: blockIdx.x, blockIdx.x + gridDim.x, ... (one when the grid covers them all)
   const int nob = (g.outer_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int64_t ob_rows = (int64_t)gridDim.x * outer_tile(MW);
+  const int64_t ob_rows = (int64_t)gridDim.x * outer_tile(GW);
 
   // Waves 0..3 are MFMA waves; waves 4.. (kLoaders of them) are LOADER waves that only issue the LDS-DMA of the next tile
   // (a global_load_lds costs its issuing wave ~100 cycles, which an in-order MFMA wave cannot hide: with
   // the DMA issued from the MFMA waves this kernel lost 14 %).  Chunk c (1 KiB = 4 tile rows): lane
   // (r = lane >> 4, s = lane & 15) fills physical 16-byte slot s of row 4c + r with logical slot
   // s ^ (row & 15).
-  if (wave >= 4) {
+  if (wave >= NW) {
     __builtin_amdgcn_s_setprio(3);  // few instructions, but they gate everyone: win the issue arbitration
     // generic (bounds-checked) issue of one tile: used for edge tiles only
     int64_t row0 = row_first;  // outer tile being STAGED (runs ahead of the one being multiplied)
     auto stage_checked = [&](int buf, int kt) {
       char* rt = smem + buf * STAGE;
       const int64_t k0 = (int64_t)kt * KT;
-      for (int c = wave - 4; c < (ALIAS ? 4 * NT : 16 * MW); c += kLoaders) {
+      for (int c = wave - NW; c < (ALIAS ? 4 * NT : 16 * GW); c += kLoaders) {
         const int row = 4 * c + (lane >> 4);
         const int ls = (lane & 15) ^ (row & 15);
         const int64_t grow = row0 + row;
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
         glds16(src, rt + c * 1024);
       }
       if constexpr (!ALIAS)
-        for (int c = wave - 4; c < 4 * NT; c += kLoaders) {
+        for (int c = wave - NW; c < 4 * NT; c += kLoaders) {
           const int row = 4 * c + (lane >> 4);
           const int ls = (lane & 15) ^ (row & 15);
           glds16(g.x + (col0 + row) * g.x_ld + k0 + ls * VEC, rt + BIG + c * 1024);
@@ -321,10 +326,10 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
     // pattern streams: chunk c covers tile rows 4c..4c+3 and (row & 15) repeats every 4 chunks; loader lw
     // of NL owns chunks c = lw + NL*i, i.e. NV = 4/NL pattern variants, each repeating every 16 rows
     constexpr int NL = kLoaders, NV = 4 / NL;
-    const int lw = wave - 4;
+    const int lw = wave - NW;
     // alias: only the 16 * NT rows that exist as (zero padded) columns of the sketch are staged; the rows above them
     // feed accumulators whose outer index is >= r_rows and is never stored
-    DmaStream<NV, ALIAS ? NT : 4 * MW, NL> big;
+    DmaStream<NV, ALIAS ? NT : 4 * GW, NL> big;
     DmaStream<NV, NT, NL> sk;
     // rotated reduction order (g.rotate): workgroup x starts at tile x mod nk and wraps.  With a short row (n = 512:
     // 2 KB) every workgroup of a launch would otherwise sit on the same 256-byte phase of its rows at the same time,
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
     sk.step = 16 * g.x_ld * (int64_t)sizeof(T);
     sk.adv = KT * (int64_t)sizeof(T);
     // alias: the host guarantees 16 * NT allocated columns (x.cols_alloc), all of them readable
-    bool rows_inside = ALIAS ? true : (row0 + outer_tile(MW) <= g.r_rows);
+    bool rows_inside = ALIAS ? true : (row0 + outer_tile(GW) <= g.r_rows);
     auto stage_tile = [&](int buf, int kt) {
       char* rt = smem + buf * STAGE;
       if (rows_inside && (int64_t)(kt + 1) * KT <= g.r_cols_readable) {
@@ -364,9 +369,9 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
       }
     };
     // ring of NSTAGE buffers: tiles i+1 .. i+NSTAGE-1 are in flight while the MFMA waves work on tile i
-    constexpr int NSTAGE = ALIAS ? 3 : gemm_stages(MW, NT);
-    static_assert((16 * MW) % kLoaders == 0 && (4 * NT) % kLoaders == 0, "chunks must split evenly over the loaders");
-    constexpr int DPL = ALIAS ? NT : (16 * MW + 4 * NT) / kLoaders;  // DMA instructions per loader wave per tile
+    constexpr int NSTAGE = ALIAS ? 3 : gemm_stages(GW, NT);
+    static_assert((16 * GW) % kLoaders == 0 && (4 * NT) % kLoaders == 0, "chunks must split evenly over the loaders");
+    constexpr int DPL = ALIAS ? NT : (16 * GW + 4 * NT) / kLoaders;  // DMA instructions per loader wave per tile
     // the tiles of all outer tiles of this workgroup form ONE sequence through the ring
     const int nflat = nob * nk;
     const int64_t wrap = -(int64_t)nk * KT * (int64_t)sizeof(T);  // back to the first tile of the reduction range
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
         row0 += ob_rows;
 #pragma unroll
         for (int pv = 0; pv < NV; ++pv) big.ptr[pv] += big_jump;
-        if constexpr (!ALIAS) rows_inside = row0 + outer_tile(MW) <= g.r_rows;
+        if constexpr (!ALIAS) rows_inside = row0 + outer_tile(GW) <= g.r_rows;
       }
     };
     for (int t = 0; t < NSTAGE - 1 && t < nflat; ++t) stage_next(t % NSTAGE);
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
       // tile i must have landed; the (NSTAGE-2) younger tiles may stay in flight (vmcnt counts in issue order)
       if (NSTAGE > 2 && i + NSTAGE - 2 < nflat) {
         if (g.debug_flags & 2)
-          wait_vmcnt<(NSTAGE - 2) * (16 * MW / kLoaders)>();
+          wait_vmcnt<(NSTAGE - 2) * (16 * GW / kLoaders)>();
         else if (g.debug_flags & 4)
           wait_vmcnt<(NSTAGE - 2) * (4 * NT / kLoaders)>();
         else
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
     });
   };
 
-  constexpr int NSTAGE_C = ALIAS ? 3 : gemm_stages(MW, NT);
+  constexpr int NSTAGE_C = ALIAS ? 3 : gemm_stages(GW, NT);
   int buf = 0;
   int64_t row0 = row_first;
   for (int ob = 0; ob < nob; ++ob, row0 += ob_rows) {
@@ -518,39 +523,41 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_nn_kernel(GemmArgs<T
 // ---------------------------------------------------------------------------------------------
 // gemm_tn: grid = (ceil(R_cols/64), column blocks, nsplit); reduction over the rows of R
 // ---------------------------------------------------------------------------------------------
-template <class T, int MW, int NT>
-__global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T> g) {
+template <class T, int MW, int NT, int NW = 4>
+__global__ __launch_bounds__(64 * (NW + kLoaders)) void gemm_tn_kernel(GemmArgs<T> g) {
+  constexpr int GW = MW * NW / 4;  // see gemm_nn_kernel
+  static_assert(NW == 4 || NW == 8, "4 or 8 MFMA waves");
   typedef typename MT<T>::acc_t acc_t;
   typedef typename MT<T>::vec_t vec_t;
   constexpr int VEC = MT<T>::VEC;
   constexpr int KT = MT<T>::KT;
-  constexpr int STAGE = stage_bytes(MW, NT);
-  constexpr int BIG = big_tile_bytes(MW);
-  constexpr int RBT = 64 * MW * (int)sizeof(T);  // bytes per row of the big tile (64*MW outer columns)
+  constexpr int STAGE = stage_bytes(GW, NT);
+  constexpr int BIG = big_tile_bytes(GW);
+  constexpr int RBT = 64 * GW * (int)sizeof(T);  // bytes per row of the big tile (64*GW outer columns)
   constexpr int LPR = RBT / 16;                  // lanes per row in one DMA instruction (16..128)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (g.run_if && *g.run_if == 0) return;  // uniform over the grid
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t n_first = (int64_t)blockIdx.x * outer_tile(MW);
+  const int64_t n_first = (int64_t)blockIdx.x * outer_tile(GW);
   const int64_t col0 = g.col_base + (int64_t)blockIdx.y * (NT * 16);
   const int t_begin = blockIdx.z * g.tiles_per_split;
   const int t_end = min(t_begin + g.tiles_per_split, g.tiles_total);
   const int nk = t_end - t_begin;
   // outer tiles of this workgroup: blockIdx.x, blockIdx.x + gridDim.x, ... (see gemm_nn_kernel)
   const int nob = (g.outer_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int64_t ob_cols = (int64_t)gridDim.x * outer_tile(MW);
+  const int64_t ob_cols = (int64_t)gridDim.x * outer_tile(GW);
 
   // The loader wave (4) issues the LDS-DMA, waves 0..3 run the MFMAs (see gemm_nn).  The big tile is a
   // row-linear LDS image of KT reduction rows x (64*MW outer columns); 16-byte slot lin = 64c + lane of
   // chunk c holds logical slot (lin % LPR) ^ tswz(row) of row lin / LPR.
-  if (wave >= 4) {
+  if (wave >= NW) {
     __builtin_amdgcn_s_setprio(3);
     int64_t n0 = n_first;  // outer tile being STAGED
     auto stage_checked = [&](int buf, int mt) {
       char* rt = smem + buf * STAGE;
       const int64_t m0 = (int64_t)mt * KT;
-      for (int c = wave - 4; c < 16 * MW; c += kLoaders) {
+      for (int c = wave - NW; c < 16 * GW; c += kLoaders) {
         const int lin = c * 64 + lane;
         const int row = lin / LPR;
         const int lsb = (lin % LPR) ^ MT<T>::tswz(row);
@@ -559,7 +566,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
         const T* src = (grow < g.r_rows && nn < g.r_cols_readable) ? g.r + grow * g.r_ld + nn : g.zero;
         glds16(src, rt + c * 1024);
       }
-      for (int c = wave - 4; c < 4 * NT; c += kLoaders) {
+      for (int c = wave - NW; c < 4 * NT; c += kLoaders) {
         const int row = 4 * c + (lane >> 4);
         const int ls = (lane & 15) ^ (row & 15);
         glds16(g.x + (col0 + row) * g.x_ld + m0 + ls * VEC, rt + BIG + c * 1024);
@@ -568,8 +575,8 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
     // big tile: the (row, swizzle) pattern of chunk c repeats every 8 chunks = 8*64/LPR tile rows; loader lw
     // of NL owns chunks c = lw + NL*i
     constexpr int NL = kLoaders, NVB = 8 / NL, NV = 4 / NL;
-    const int lw = wave - 4;
-    DmaStream<NVB, 2 * MW, NL> big;
+    const int lw = wave - NW;
+    DmaStream<NVB, 2 * GW, NL> big;
     DmaStream<NV, NT, NL> sk;
 #pragma unroll
     for (int pv = 0; pv < NVB; ++pv) {
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
     big.adv = (int64_t)KT * g.r_ld * (int64_t)sizeof(T);
     sk.step = 16 * g.x_ld * (int64_t)sizeof(T);
     sk.adv = KT * (int64_t)sizeof(T);
-    bool cols_inside = n0 + outer_tile(MW) <= g.r_cols_readable;
+    bool cols_inside = n0 + outer_tile(GW) <= g.r_cols_readable;
     auto stage_tile = [&](int buf, int mt) {
       char* rt = smem + buf * STAGE;
       if (cols_inside && (int64_t)(mt + 1) * KT <= g.r_rows) {
@@ -603,9 +610,9 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
       }
     };
     // ring of NSTAGE buffers: tiles i+1 .. i+NSTAGE-1 are in flight while the MFMA waves work on tile i
-    constexpr int NSTAGE = gemm_stages(MW, NT);
-    static_assert((16 * MW) % kLoaders == 0 && (4 * NT) % kLoaders == 0, "chunks must split evenly over the loaders");
-    constexpr int DPL = (16 * MW + 4 * NT) / kLoaders;  // DMA instructions per loader wave per tile
+    constexpr int NSTAGE = gemm_stages(GW, NT);
+    static_assert((16 * GW) % kLoaders == 0 && (4 * NT) % kLoaders == 0, "chunks must split evenly over the loaders");
+    constexpr int DPL = (16 * GW + 4 * NT) / kLoaders;  // DMA instructions per loader wave per tile
     const int nflat = nob * nk;
     const int64_t big_jump = (ob_cols - (int64_t)nk * KT * g.r_ld) * (int64_t)sizeof(T);
     const int64_t sk_jump = -(int64_t)nk * KT * (int64_t)sizeof(T);
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
         for (int pv = 0; pv < NVB; ++pv) big.ptr[pv] += big_jump;
 #pragma unroll
         for (int pv = 0; pv < NV; ++pv) sk.ptr[pv] += sk_jump;
-        cols_inside = n0 + outer_tile(MW) <= g.r_cols_readable;
+        cols_inside = n0 + outer_tile(GW) <= g.r_cols_readable;
       }
     };
     for (int t = 0; t < NSTAGE - 1 && t < nflat; ++t) stage_next(t % NSTAGE);
@@ -728,7 +735,7 @@ __global__ __launch_bounds__(64 * (4 + kLoaders)) void gemm_tn_kernel(GemmArgs<T
     for (int i = 0; i < nk; ++i) {
       wg_barrier();
       compute(buf, i > 0);
-      buf = buf + 1 == gemm_stages(MW, NT) ? 0 : buf + 1;
+      buf = buf + 1 == gemm_stages(GW, NT) ? 0 : buf + 1;
     }
     if constexpr (kDefer > 0) {
       if (nk > 0) static_for<NS - kDefer, NS>(mfma_step);

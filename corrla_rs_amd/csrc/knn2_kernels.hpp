@@ -15,13 +15,14 @@
 //    query's current n-th exact distance; margin 2e-4 bounds every rounding of the filter) -- conservative, never exact.
 //  * SURVIVORS are only appended (4-byte index, ballot + popcount, no sorting) to a per-query candidate buffer.
 //  * FLUSHES are batched and ALIGNED: after chunks 1, 2, 4, 8, ... (the expected number of survivors per query between
-//    chunk c and 2c is n ln 2) every wave empties the buffers of its 16 queries at the same time -- the waves of a
+//    chunk c and 2c is n ln 2) every wave empties the buffers of its 32 queries at the same time -- the waves of a
 //    workgroup share every staged chunk, so a flush that stalled one of them would stall them all.  A flush takes 64
 //    candidates at a time, lane = candidate: exact f64 distance from the uncentred rows, a 64-key bitonic sort of
 //    (distance, index), and a two-stage bitonic merge into the query's sorted list of 128 -- ~40 compare-exchange steps
 //    for 64 candidates instead of 64 serial insertions.  A buffer that fills between flush points flushes on the spot.
-//  * 16 scanning waves (256 queries) per workgroup share every staged chunk, one workgroup per CU, persistent over the
-//    query tiles (with 8 waves the scan sat on the LDS-DMA fill rate: 2 TB staged for 1e6 x 1e6 at ~6.4 TB/s).
+//  * 16 scanning waves x 32 queries (two MFMA row tiles: every fragment read serves both) per workgroup share every staged
+//    chunk, one workgroup per CU, persistent over the query tiles.  (8 waves x 16 queries sat on the LDS-DMA fill rate:
+//    2 TB staged for 1e6 x 1e6 at ~6.4 TB/s; 16 waves x 16 queries on the fragment reads: 256 KiB per chunk and CU.)
 // The neighbour SETS are exact whatever the filter does (a pair the filter drops is farther than the n-th exact
 // distance by more than the bound on the filter's error); the ORDER inside a set is (exact distance, index).
 // Limits: k <= 64, n_nbrs <= 128 (the host falls back to knn_mfma_kernel beyond).
@@ -35,9 +36,13 @@
 namespace corrla {
 namespace k {
 
-constexpr int kK2Waves = 16;            // scanning waves per workgroup (they share every staged chunk: the LDS-DMA fill
+constexpr int kK2Waves = 12;            // scanning waves per workgroup = 3 per SIMD (168 VGPRs: at 4 per SIMD the query fragments spill);
                                         // rate, ~25 GB/s per CU, bounded the scan at 8)
-constexpr int kK2Q = 16 * kK2Waves;     // queries per workgroup tile
+constexpr int kK2RowTiles = 2;          // 16-query MFMA row tiles per wave: every B fragment read from LDS serves both
+                                        // (with one, the 16 waves' fragment reads -- 256 KiB per chunk and CU at 128 B/clk
+                                        // -- outweighed the MFMAs)
+constexpr int kK2WQ = 16 * kK2RowTiles; // queries per wave
+constexpr int kK2Q = kK2WQ * kK2Waves;  // queries per workgroup tile
 constexpr int kK2Cap = 256;             // candidate slots per query between flushes
 constexpr int kK2List = 128;            // list entries per query (n_nbrs <= 128)
 constexpr int kK2Chunk = 64;            // support points per chunk
@@ -45,7 +50,8 @@ constexpr float kK2Margin = 2.0e-4f;    // bound on |d^2_filter - d^2| / (|q|^2 
 
 __host__ __device__ constexpr int k2_chunk_bytes(int s) { return s * 8192; }            // s = 32-dimension MFMA steps
 __host__ __device__ constexpr int k2_stage_bytes(int s) { return k2_chunk_bytes(s) + 256; }  // + 64 f32 norms
-__host__ __device__ constexpr int k2_lds_bytes(int s) { return 2 * k2_stage_bytes(s); }
+// two stages + one 64-coordinate f64 row per wave (the query whose candidates are being re-checked)
+__host__ __device__ constexpr int k2_lds_bytes(int s) { return 2 * k2_stage_bytes(s) + kK2Waves * 512; }
 
 struct Knn2Args {
   const __bf16* pb;   // [chunk][s][plane (hi, lo)][tile t of 16 points][lane][8]: B fragments of the centred points
@@ -162,7 +168,7 @@ __device__ __forceinline__ void k2_sort(K2Key& a, int lane) {
 }
 
 template <int S>
-__global__ __launch_bounds__(64 * kK2Waves, 4) void knn2_kernel(Knn2Args g) {
+__global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STG = k2_stage_bytes(S);
   constexpr int NDMA = S * 8;  // 1 KiB LDS-DMA instructions per chunk (fragments); + one 256-byte one for the norms
@@ -170,9 +176,9 @@ __global__ __launch_bounds__(64 * kK2Waves, 4) void knn2_kernel(Knn2Args g) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int kdim = g.k;
-  int* const cand_w = g.cand + ((int64_t)blockIdx.x * kK2Q + wave * 16) * kK2Cap;
-  double* const ld_w = g.list_d + ((int64_t)blockIdx.x * kK2Q + wave * 16) * kK2List;
-  int* const li_w = g.list_i + ((int64_t)blockIdx.x * kK2Q + wave * 16) * kK2List;
+  int* const cand_w = g.cand + ((int64_t)blockIdx.x * kK2Q + wave * kK2WQ) * kK2Cap;
+  double* const ld_w = g.list_d + ((int64_t)blockIdx.x * kK2Q + wave * kK2WQ) * kK2List;
+  int* const li_w = g.list_i + ((int64_t)blockIdx.x * kK2Q + wave * kK2WQ) * kK2List;
   const double inf = __builtin_huge_val();
 
   auto stage = [&](int buf, int64_t c) __attribute__((always_inline)) {
@@ -186,47 +192,54 @@ __global__ __launch_bounds__(64 * kK2Waves, 4) void knn2_kernel(Knn2Args g) {
   };
 
   for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-    const int64_t q0 = tile * kK2Q + wave * 16;  // this wave's 16 queries
-    // ---- A fragments: query q0 + fr, dimensions 32 s + 8 fg + j, centred, two bf16 pieces; |q - mean|^2 ----
-    bf16x8 ah[S], al[S];
-    float qn_mine = 0.f;
-    {
-      const bool qv = q0 + fr < g.n_q;
+    const int64_t q0 = tile * kK2Q + wave * kK2WQ;  // this wave's 32 queries: local query qi = 16 mw + (row of tile mw)
+    // ---- A fragments: query q0 + 16 mw + fr, dimensions 32 s + 8 fg + j, centred, two bf16 pieces; |q - mean|^2 ----
+    bf16x8 ah[kK2RowTiles][S], al[kK2RowTiles][S];
+    float qn_mine[kK2RowTiles];
+#pragma unroll
+    for (int mw = 0; mw < kK2RowTiles; ++mw) {
+      const int64_t q = q0 + 16 * mw + fr;
+      const bool qv = q < g.n_q;
+      float qn = 0.f;
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int d = 32 * s + 8 * fg + j;
-          v[j] = (qv && d < kdim) ? (float)(g.xq[(q0 + fr) * kdim + d] - g.mean[d]) : 0.0f;
-          qn_mine += v[j] * v[j];
+          v[j] = (qv && d < kdim) ? (float)(g.xq[q * kdim + d] - g.mean[d]) : 0.0f;
+          qn += v[j] * v[j];
         }
         bf16x8 f2[2];
         mx_split8<2>(v, f2);
-        ah[s] = f2[0];
-        al[s] = f2[1];
+        ah[mw][s] = f2[0];
+        al[mw][s] = f2[1];
       }
-      qn_mine += __shfl_xor(qn_mine, 16, 64);
-      qn_mine += __shfl_xor(qn_mine, 32, 64);  // every lane with this fr now holds |q_fr|^2 (f32: inside the margin)
+      qn += __shfl_xor(qn, 16, 64);
+      qn += __shfl_xor(qn, 32, 64);  // every lane with this fr now holds |q_fr|^2 (f32: inside the margin)
+      qn_mine[mw] = qn;
     }
-    // D layout: column (point) = lane & 15, row (query) = 4 fg + r
+    // D layout of row tile mw: column (point) = lane & 15, row (query) = 16 mw + 4 fg + r; per-query state at [4 mw + r]
     // (ext-vector registers with constant indices: plain arrays captured by the flush lambdas ended up in scratch)
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
     // The filter per pair:  d^2_filter - margin (qn + pn) < tau   <=>   q.p > cq + cp  with
     //   cq = ((1 - margin) qn - tau) / 2  per query (changes at a flush),  cp = (1 - margin) pn / 2  per point:
     // one add and one compare per pair, the compare writing the lane mask the slow path needs anyway.
     // cq = -inf while the list is not full (everything passes), +inf for the padding queries of the last tile
     // (nothing passes); padding points carry pn = +inf, hence cp = +inf.
-    f32x4 qn_r, cq_r;
-    i32x4 cnt_r;
+    f32x8 qn_r, cq_r;
+    i32x8 cnt_r;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      qn_r[r] = __shfl(qn_mine, 4 * fg + r, 64);
-      cq_r[r] = (q0 + 4 * fg + r < g.n_q) ? -__builtin_huge_valf() : __builtin_huge_valf();
-      cnt_r[r] = 0;
-    }
+    for (int mw = 0; mw < kK2RowTiles; ++mw)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        qn_r[4 * mw + r] = __shfl(qn_mine[mw], 4 * fg + r, 64);
+        cq_r[4 * mw + r] = (q0 + 16 * mw + 4 * fg + r < g.n_q) ? -__builtin_huge_valf() : __builtin_huge_valf();
+        cnt_r[4 * mw + r] = 0;
+      }
     // empty lists
-    for (int e = lane; e < 16 * kK2List; e += 64) {
+    for (int e = lane; e < kK2WQ * kK2List; e += 64) {
       __hip_atomic_store(ld_w + e, inf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(li_w + e, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -239,7 +252,13 @@ __global__ __launch_bounds__(64 * kK2Waves, 4) void knn2_kernel(Knn2Args g) {
       l0.i = __hip_atomic_load(li_w + qi * kK2List + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       l1.d = __hip_atomic_load(ld_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       l1.i = __hip_atomic_load(li_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double* qp = g.xq + q * kdim;
+      // the query's row goes to LDS once (wave-private 512 bytes): the re-check reads it as broadcasts instead of holding
+      // it in registers next to the candidate's row
+      double* const qs = (double*)(smem + 2 * STG) + wave * 64;
+      qs[lane] = lane < kdim ? g.xq[q * kdim + lane] : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       for (int b0 = 0; b0 < ncand; b0 += 64) {
         K2Key c;
         c.d = inf;
@@ -249,13 +268,27 @@ __global__ __launch_bounds__(64 * kK2Waves, 4) void knn2_kernel(Knn2Args g) {
           const double* pp = g.x + (int64_t)c.i * kdim;
           double s0 = 0.0, s1 = 0.0;
           int d = 0;
+          // 16 coordinates per memory round trip (the plain loop below waits for every pair: 32 dependent round trips
+          // per batch at k = 64, which was most of the scan's time); same summation order: even coordinates into s0, odd
+          // ones into s1, ascending
+          for (; d + 16 <= kdim; d += 16) {
+            double pv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) pv[j] = pp[d + j];
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+              const double a0 = pv[j] - qs[d + j], a1 = pv[j + 1] - qs[d + j + 1];
+              s0 += a0 * a0;
+              s1 += a1 * a1;
+            }
+          }
           for (; d + 1 < kdim; d += 2) {
-            const double a0 = pp[d] - qp[d], a1 = pp[d + 1] - qp[d + 1];
+            const double a0 = pp[d] - qs[d], a1 = pp[d + 1] - qs[d + 1];
             s0 += a0 * a0;
             s1 += a1 * a1;
           }
           if (d < kdim) {
-            const double a0 = pp[d] - qp[d];
+            const double a0 = pp[d] - qs[d];
             s0 += a0 * a0;
           }
           c.d = s0 + s1;
@@ -289,9 +322,15 @@ __global__ __launch_bounds__(64 * kK2Waves, 4) void knn2_kernel(Knn2Args g) {
     auto flush_wave = [&](int least) __attribute__((always_inline)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's candidate stores have left it
 #pragma unroll 1
-      for (int qi = 0; qi < 16; ++qi) {
-        const int r = qi & 3, gq = qi >> 2;
-        const int mine = r == 0 ? cnt_r[0] : (r == 1 ? cnt_r[1] : (r == 2 ? cnt_r[2] : cnt_r[3]));
+      for (int qi = 0; qi < kK2WQ; ++qi) {
+        const int gq = (qi >> 2) & 3, e = 4 * (qi >> 4) + (qi & 3);  // lane group and state element of the query
+        int mine = cnt_r[0];
+        float qn_q = qn_r[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) {
+          mine = e == u ? cnt_r[u] : mine;
+          qn_q = e == u ? qn_r[u] : qn_q;
+        }
         const int nc = __shfl(mine, 16 * gq, 64);
         if (nc < least || nc == 0) continue;  // uniform
         const double tau = flush_query(qi, nc);
@@ -300,12 +339,12 @@ __global__ __launch_bounds__(64 * kK2Waves, 4) void knn2_kernel(Knn2Args g) {
         float tf = (float)tau;
         if ((double)tf < tau) tf = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, tf) + 1u);  // tau >= 0: next float up
         if (fg == gq) {
-          const float qn_q = r == 0 ? qn_r[0] : (r == 1 ? qn_r[1] : (r == 2 ? qn_r[2] : qn_r[3]));
           const float cq = tf < __builtin_huge_valf() ? 0.5f * ((1.0f - kK2Margin) * qn_q - tf) : -__builtin_huge_valf();
-          if (r == 0) { cq_r[0] = cq; cnt_r[0] = 0; }
-          if (r == 1) { cq_r[1] = cq; cnt_r[1] = 0; }
-          if (r == 2) { cq_r[2] = cq; cnt_r[2] = 0; }
-          if (r == 3) { cq_r[3] = cq; cnt_r[3] = 0; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            cq_r[u] = e == u ? cq : cq_r[u];
+            cnt_r[u] = e == u ? 0 : cnt_r[u];
+          }
         }
       }
     };
@@ -316,53 +355,66 @@ __global__ __launch_bounds__(64 * kK2Waves, 4) void knn2_kernel(Knn2Args g) {
       __syncthreads();                                    // chunk c is complete; every wave is done with chunk c - 1
       if (c + 1 < g.nchunks) stage((int)((c + 1) & 1), c + 1);
       const char* st = smem + (int)(c & 1) * STG;
-      f32x4 acc[4];
+      f32x4 acc[kK2RowTiles][4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0, 0, 0, 0};
+      for (int mw = 0; mw < kK2RowTiles; ++mw)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mw][t] = (f32x4){0, 0, 0, 0};
 #pragma unroll
       for (int s = 0; s < S; ++s)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const bf16x8 bh = *(const bf16x8*)(st + ((s * 2 + 0) * 4 + t) * 1024 + lane * 16);
           const bf16x8 bl = *(const bf16x8*)(st + ((s * 2 + 1) * 4 + t) * 1024 + lane * 16);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s], bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bl, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s], bh, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int mw = 0; mw < kK2RowTiles; ++mw) {
+            acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mw][s], bh, acc[mw][t], 0, 0, 0);
+            acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mw][s], bl, acc[mw][t], 0, 0, 0);
+            acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mw][s], bh, acc[mw][t], 0, 0, 0);
+          }
         }
-      unsigned long long hm[4][4];
-      unsigned long long any = 0;
+      float cp[4];
+      unsigned long long vm[4];  // lanes whose point of column tile t exists (padding points of the last chunk: pn = +inf)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float pnv = *(const float*)(st + k2_chunk_bytes(S) + (16 * t + fr) * 4);  // +inf for padding points
-        const float cp = (0.5f * (1.0f - kK2Margin)) * pnv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // negated comparison: a NaN goes through to the exact re-check; cq + cp = +inf never passes (inf - inf = NaN
-          // cannot occur: cq = -inf only meets finite cp or cp = +inf of a padding point, which the second test drops)
-          hm[t][r] = __ballot(!(acc[t][r] <= cq_r[r] + cp) && pnv < __builtin_huge_valf());
-          any |= hm[t][r];
-        }
+        const float pnv = *(const float*)(st + k2_chunk_bytes(S) + (16 * t + fr) * 4);
+        cp[t] = (0.5f * (1.0f - kK2Margin)) * pnv;
+        vm[t] = __ballot(pnv < __builtin_huge_valf());
       }
-      if (any != 0) {  // uniform
-        const int base = (int)(c * kK2Chunk);
+      const int base = (int)(c * kK2Chunk);
+#pragma unroll
+      for (int mw = 0; mw < kK2RowTiles; ++mw) {
+        unsigned long long hm[4][4];
+        unsigned long long any = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const unsigned long long m = hm[t][r];
-            if (m == 0) continue;  // uniform
-            const unsigned gm = (unsigned)(m >> (16 * fg)) & 0xffffu;  // the 16 points of MY query (4 fg + r)
-            const bool h = (gm >> fr) & 1u;
-            const int slot = cnt_r[r] + __popc(gm & ((1u << fr) - 1u));
-            if (h && slot < kK2Cap) cand_w[(4 * fg + r) * kK2Cap + slot] = base + 16 * t + fr;
-            cnt_r[r] += __popc(gm);
+            // negated comparison: a NaN goes through to the exact re-check; cq + cp = +inf never passes (inf - inf = NaN
+            // only where cq = -inf meets the cp = +inf of a padding point, which vm drops)
+            hm[t][r] = __ballot(!(acc[mw][t][r] <= cq_r[4 * mw + r] + cp[t])) & vm[t];
+            any |= hm[t][r];
           }
+        if (any != 0) {  // uniform
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const unsigned long long m = hm[t][r];
+              if (m == 0) continue;  // uniform
+              const unsigned gm = (unsigned)(m >> (16 * fg)) & 0xffffu;  // the 16 points of MY query (16 mw + 4 fg + r)
+              const bool h = (gm >> fr) & 1u;
+              const int slot = cnt_r[4 * mw + r] + __popc(gm & ((1u << fr) - 1u));
+              if (h && slot < kK2Cap) cand_w[(16 * mw + 4 * fg + r) * kK2Cap + slot] = base + 16 * t + fr;
+              cnt_r[4 * mw + r] += __popc(gm);
+            }
+        }
       }
       // aligned flush points: after chunks 1, 2, 4, 8, ... and the last one; in between only a buffer that could
       // overflow in the next chunk (64 more candidates) is flushed
       const int64_t done = c + 1;
       const bool point = (done & (done - 1)) == 0 || done == g.nchunks;
-      const int cmax = max(max(cnt_r[0], cnt_r[1]), max(cnt_r[2], cnt_r[3]));
+      const int cmax = max(max(max(cnt_r[0], cnt_r[1]), max(cnt_r[2], cnt_r[3])), max(max(cnt_r[4], cnt_r[5]), max(cnt_r[6], cnt_r[7])));
       // (one call site: the per-query registers above stay registers only if the flush code is inlined once)
       const int least = point ? 1 : (__any(cmax > kK2Cap - kK2Chunk) ? kK2Cap - kK2Chunk + 1 : 0);
       if (least) flush_wave(least);
@@ -370,7 +422,7 @@ __global__ __launch_bounds__(64 * kK2Waves, 4) void knn2_kernel(Knn2Args g) {
     // ---- results: the first n_nbrs entries of every list, nearest first ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
-    for (int qi = 0; qi < 16; ++qi) {
+    for (int qi = 0; qi < kK2WQ; ++qi) {
       const int64_t q = q0 + qi;
       if (q >= g.n_q) break;  // uniform
       for (int e = lane; e < g.n_nbrs; e += 64)

@@ -53,7 +53,9 @@ __host__ __device__ constexpr int mx_plane_bytes(int nt) { return nt * 16 * kMxK
 // skinny operand are re-read by every workgroup, i.e. served by L2, and run one tile ahead (2 slots).  (Round 3's first
 // version had one ring of whole tiles: only 2 fit for three planes, and the DMA cost 30 % on top of the DMA-free time.)
 constexpr int kMxASlots = 3, kMxBSlots = 2;
-__host__ __device__ constexpr int mx_bslot_bytes(int nt, int np) { return np * mx_plane_bytes(nt); }
+// np = 0: the EXACT f32 variant of the same skeleton (v_mfma_f32_16x16x4_f32): the skinny operand is staged as f32, in the
+// nn layout of the big image (columns of X = rows of 128 bytes)
+__host__ __device__ constexpr int mx_bslot_bytes(int nt, int np) { return np ? np * mx_plane_bytes(nt) : nt * 16 * kMxKT * 4; }
 __host__ __device__ constexpr int mx_lds_bytes(int nt, int np) { return kMxASlots * kMxBigBytes + kMxBSlots * mx_bslot_bytes(nt, np) + 1024; }
 
 // reduction index (inside a 32-deep tile) that position p = 8 g + j of a plane row / MFMA fragment holds
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
     const int lw = wave - kMxWaves;
     constexpr int NBIG = kMxBigBytes / 1024;                        // 32 chunks of the big operand per tile
     constexpr int DA = NBIG / kMxLoaders;                           // 8 per loader
-    constexpr int NSK = NP * NT;                                    // plane chunks per tile
+    constexpr int NSK = NP ? NP * NT : 2 * NT;                      // plane chunks per tile (f32 image: 2 KiB per column tile)
     constexpr int DB = (NSK + kMxLoaders - 1) / kMxLoaders;         // per loader (padded)
     char* scratch = smem + BRING + kMxBSlots * BSLOT;
     auto stage_big = [&](int slot, int kt) {
@@ -264,10 +266,16 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
           glds16(g.zero, scratch);  // keeps the per-tile DMA count uniform over the loaders
           continue;
         }
-        const int p = cc / NT, ct = cc - p * NT;
-        const int row = 16 * ct + (lane >> 2);
-        const int ls = (lane & 3) ^ mx_plane_swz(row);
-        glds16(g.planes + p * g.plane_stride + (int64_t)row * g.x_ld + k0 + 8 * ls, st + p * PLANE + ct * 1024);
+        if constexpr (NP == 0) {
+          const int row = 8 * cc + (lane >> 3);  // column of X
+          const int ls = (lane & 7) ^ mx_big_swz(row);
+          glds16((const float*)g.planes + (int64_t)row * g.x_ld + k0 + 4 * ls, st + cc * 1024);
+        } else {
+          const int p = cc / NT, ct = cc - p * NT;
+          const int row = 16 * ct + (lane >> 2);
+          const int ls = (lane & 3) ^ mx_plane_swz(row);
+          glds16(g.planes + p * g.plane_stride + (int64_t)row * g.x_ld + k0 + 8 * ls, st + p * PLANE + ct * 1024);
+        }
       }
     };
     // issue order (vmcnt retires in order):  B(0) A(0) A(1) | then per tile i, after its barrier:  B(i+1) A(i+2).
@@ -337,45 +345,67 @@ __global__ __launch_bounds__(64 * (kMxWaves + kMxLoaders), 3) void gemm_bf16s_ke
         }
       }
     }
-    bf16x8 bk[T1][NP];
+    if constexpr (NP == 0) {
+      // exact f32: 8 x v_mfma_f32_16x16x4_f32 per (row tile, column tile); step s multiplies reduction index kmap(g, s) on
+      // both sides.  The fragment of the next column tile is read under the MFMAs of this one.
+      const unsigned x_base = (unsigned)(fr * 128 + ((fg ^ mx_big_swz(fr)) << 4));
+      f32x4 n0 = *(const f32x4*)(sb + x_base), n1 = *(const f32x4*)(sb + (x_base ^ 64u));
 #pragma unroll
-    for (int t = 0; t < T1; ++t)
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 c0 = n0, c1 = n1;
+        if (t + 1 < NT) {
+          n0 = *(const f32x4*)(sb + (x_base + (t + 1) * 2048));
+          n1 = *(const f32x4*)(sb + ((x_base + (t + 1) * 2048) ^ 64u));
+        }
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bk[t][p] = *(const bf16x8*)(sb + b_base + t * 1024 + p * PLANE);
-    bf16x8 af[kMxRowTiles][NP];
-    mx_split8<NP>(xr[0], af[0]);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int mw = 0; mw < kMxRowTiles; ++mw) {
 #pragma unroll
-    for (int t = 0; t < T1; ++t) acc[0][t] = mx_products<NP>(af[0], bk[t], acc[0][t]);
-    mx_split8<NP>(xr[1], af[1]);
-    bf16x8 bn[NP];
-    if constexpr (T1 < NT) {
+          for (int s4 = 0; s4 < 4; ++s4) acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[mw][s4], c0[s4], acc[mw][t], 0, 0, 0);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bn[p] = *(const bf16x8*)(sb + b_base + T1 * 1024 + p * PLANE);
-    }
-    // hipcc hoists the whole second split above the first MFMA otherwise: one MFMA, then two of the split's VALU
-    // instructions (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles), the plane reads of the next column tile
-    // in the last gaps
-#pragma unroll
-    for (int i = 0; i < T1 * (NP == 3 ? 6 : 3); ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 2 : 3, 0);  // VALU
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);  // DS read
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < T1; ++t) acc[1][t] = mx_products<NP>(af[1], bk[t], acc[1][t]);
-#pragma unroll
-    for (int t = T1; t < NT; ++t) {
-      bf16x8 bc[NP];
-#pragma unroll
-      for (int p = 0; p < NP; ++p) bc[p] = bn[p];
-      if (t + 1 < NT) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) bn[p] = *(const bf16x8*)(sb + b_base + (t + 1) * 1024 + p * PLANE);
+          for (int s4 = 0; s4 < 4; ++s4) acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[mw][4 + s4], c1[s4], acc[mw][t], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int mw = 0; mw < kMxRowTiles; ++mw) acc[mw][t] = mx_products<NP>(af[mw], bc, acc[mw][t]);
+    } else {
+      bf16x8 bk[T1][NP];
+  #pragma unroll
+      for (int t = 0; t < T1; ++t)
+  #pragma unroll
+        for (int p = 0; p < NP; ++p) bk[t][p] = *(const bf16x8*)(sb + b_base + t * 1024 + p * PLANE);
+      bf16x8 af[kMxRowTiles][NP];
+      mx_split8<NP>(xr[0], af[0]);
+      __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+      for (int t = 0; t < T1; ++t) acc[0][t] = mx_products<NP>(af[0], bk[t], acc[0][t]);
+      mx_split8<NP>(xr[1], af[1]);
+      bf16x8 bn[NP];
+      if constexpr (T1 < NT) {
+  #pragma unroll
+        for (int p = 0; p < NP; ++p) bn[p] = *(const bf16x8*)(sb + b_base + T1 * 1024 + p * PLANE);
+      }
+      // hipcc hoists the whole second split above the first MFMA otherwise: one MFMA, then two of the split's VALU
+      // instructions (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles), the plane reads of the next column tile
+      // in the last gaps
+  #pragma unroll
+      for (int i = 0; i < T1 * (NP == 3 ? 6 : 3); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 2 : 3, 0);  // VALU
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);  // DS read
+      __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+      for (int t = 0; t < T1; ++t) acc[1][t] = mx_products<NP>(af[1], bk[t], acc[1][t]);
+  #pragma unroll
+      for (int t = T1; t < NT; ++t) {
+        bf16x8 bc[NP];
+  #pragma unroll
+        for (int p = 0; p < NP; ++p) bc[p] = bn[p];
+        if (t + 1 < NT) {
+  #pragma unroll
+          for (int p = 0; p < NP; ++p) bn[p] = *(const bf16x8*)(sb + b_base + (t + 1) * 1024 + p * PLANE);
+        }
+  #pragma unroll
+        for (int mw = 0; mw < kMxRowTiles; ++mw) acc[mw][t] = mx_products<NP>(af[mw], bc, acc[mw][t]);
+      }
     }
     abuf = abuf + 1 == kMxASlots ? 0 : abuf + 1;
     bbuf = bbuf + 1 == kMxBSlots ? 0 : bbuf + 1;

@@ -272,3 +272,32 @@ def test_quadratic_fits_beyond_the_lds_limit_of_the_normal_equations(ctx, k, n, 
     y2 = 0.5 * np.einsum("ni,ij,nj->n", x, qm, x) + x @ b + 3.0
     g2, _ = ctx.grad_mat(x, y2, 2, n_nbrs, x[:nq])
     assert np.max(np.abs(g2 - (x[:nq] @ qm + b).T)) <= 1e-6 * np.abs(g2).max()
+
+
+# ---- f64 tall products with two MFMA waves per SIMD (round 3) --------------------------------------------------------
+@pytest.mark.parametrize("m,n,l", [
+    (4096, 1024, 138),     # 9 column tiles, both kernels on the 128-index tile
+    (1000, 700, 266),      # ragged edges, two column blocks (9 + 8 tiles)
+    (65536, 512, 40),      # persistent launch over the outer tiles (short reduction)
+    (300, 20000, 17),      # long reduction split over workgroups (slab reduce)
+])
+def test_f64_products_with_eight_mfma_waves_are_bitwise_those_of_four(torch, monkeypatch, m, n, l):
+    """The f64 instantiations <double, 1, NT, 8 waves> (default) and <double, 2, NT, 4 waves> (CORRLA_F64_WAVES=4, round 2)
+    share the tile geometry and every accumulator's summation order, so A X and A^T Y must agree to the last bit; both
+    must agree with torch to rounding."""
+    import corrla_rs_amd as cr
+    g = torch.Generator(device="cuda").manual_seed(m + n + l)
+    a = torch.randn((m, n), dtype=torch.float64, device="cuda", generator=g)
+    x = torch.randn((n, l), dtype=torch.float64, device="cuda", generator=g)
+    y = torch.randn((m, l), dtype=torch.float64, device="cuda", generator=g)
+    monkeypatch.setenv("CORRLA_F64_WAVES", "8")
+    c8 = cr.Context(0)
+    monkeypatch.setenv("CORRLA_F64_WAVES", "4")
+    c4 = cr.Context(0)
+    monkeypatch.delenv("CORRLA_F64_WAVES")
+    for trans, rhs in ((False, x), (True, y)):
+        z8 = c8.matmul(a, rhs, trans=trans)
+        z4 = c4.matmul(a, rhs, trans=trans)
+        ref = (a.t() if trans else a) @ rhs
+        assert torch.equal(z8, z4), float((z8 - z4).abs().max())
+        assert float((z8 - ref).abs().max()) <= 1e-11 * float(ref.abs().max())

@@ -29,12 +29,13 @@ def main():
         for n, (c, t) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
             print(f"{n:72s} {c:6d} {t / 1e3:10.1f} {t / 1e3 / c:9.2f} {100.0 * t / allns:6.2f}")
         return
-    # one rsvd call ends with column_sign + apply_column_sign x2 + copy_out x2; --call N picks the N-th call
+    # one rsvd call ends with column_sign_apply (round 2: column_sign + apply_column_sign x2) + copy_out x2; --call N picks
+    # the N-th call
     # (default: the 5th, a timed step of the default bench run after its 3 warm-up calls)
     call = 5
     if "--call" in sys.argv:
         call = int(sys.argv[sys.argv.index("--call") + 1])
-    signs = [i for i, r in enumerate(rows) if "column_sign_kernel" in r[0] and "apply" not in r[0]]
+    signs = [i for i, r in enumerate(rows) if "column_sign_apply_kernel" in r[0] or ("column_sign_kernel" in r[0] and "apply" not in r[0])]
     if len(signs) < call or call < 2:
         print("not enough rsvd calls in the trace")
         return
