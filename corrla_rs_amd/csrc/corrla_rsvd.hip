@@ -336,11 +336,24 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
       ka.list_d = (double*)dev.alloc_bytes((size_t)wgs * k::kK2Q * k::kK2List * sizeof(double));
       ka.list_i = (int*)dev.alloc_bytes((size_t)wgs * k::kK2Q * k::kK2List * sizeof(int));
       ka.nbr = nbr;
+      ka.prof = nullptr;
+      const bool k2prof = env_int("CORRLA_KNN2_PROF", 0) != 0;
+      if (k2prof) {
+        ka.prof = (unsigned long long*)dev.alloc_bytes(4 * sizeof(unsigned long long));
+        CORRLA_HIP(hipMemsetAsync(ka.prof, 0, 4 * sizeof(unsigned long long), dev.stream));
+      }
       if (S == 1)
         hipLaunchKernelGGL((k::knn2_kernel<1>), dim3((unsigned)wgs), dim3(64 * k::kK2Waves), k::k2_lds_bytes(1), dev.stream, ka);
       else
         hipLaunchKernelGGL((k::knn2_kernel<2>), dim3((unsigned)wgs), dim3(64 * k::kK2Waves), k::k2_lds_bytes(2), dev.stream, ka);
       CORRLA_HIP(hipGetLastError());
+      if (k2prof) {  // diagnostic only: synchronises
+        unsigned long long h[4];
+        CORRLA_HIP(hipMemcpyAsync(h, ka.prof, sizeof(h), hipMemcpyDeviceToHost, dev.stream));
+        CORRLA_HIP(hipStreamSynchronize(dev.stream));
+        std::fprintf(stderr, "knn2 prof (wave 0 of %lld workgroups, 100 MHz ticks): total %llu, flushes %llu (%.1f %%), chunk waits %llu (%.1f %%), "
+                     "%llu merge batches\n", (long long)wgs, h[2], h[0], 100.0 * h[0] / (double)h[2], h[1], 100.0 * h[1] / (double)h[2], h[3]);
+      }
     } else if (knn_mode == 1 || (knn_mode == 0 && n_pts < 131072)) {
       const size_t lds_knn = k::knn_lds_bytes(kk, nn);
       const int64_t knn_blocks = (n_q + k::kKnnQueries - 1) / k::kKnnQueries;

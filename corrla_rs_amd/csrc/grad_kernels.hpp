@@ -615,22 +615,24 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
 //    layout, so ONE register serves both sides of G = D^T D), loads of several neighbour groups in flight;
 //  * the design carries two more columns, the constant and y itself, so the right-hand side D^T y is row k + 1 of the
 //    same product; only the lower-triangle tiles are formed (15 for k = 64), in registers;
-//  * LDS holds the (k + 1) x (k + 3) system only (35 KB: four queries per CU), factorised left-looking with eight
-//    products in flight per lane, solved in the column-oriented form.
+//  * LDS holds the packed lower triangle of the (k + 1) x (k + 1) system and its right-hand side only (17 KB at k = 64:
+//    eight queries per CU), factorised left-looking with eight products in flight per lane, solved column-oriented.
 // NTT = 16-column tiles of the design including the constant and y: ceil((k + 2) / 16).
 template <int NTT>
-__global__ __launch_bounds__(64) void grad_fit_lin_kernel(const double* __restrict__ x, const double* __restrict__ y, int k,
+__global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __restrict__ x, const double* __restrict__ y, int k,
                                                           const double* __restrict__ xq, int64_t n_q,
                                                           const int* __restrict__ nbr, int n_nbrs, double out_scale, double* g,
                                                           int64_t ldg, int* status) {
   typedef double f64x4v __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int P = k + 1;             // unknowns: k slopes and the constant
-  const int LM = (P + 1) | 1;      // odd row pitch; column P holds the right-hand side
-  double* M = (double*)smem;       // [P][LM]
-  double* beta = M + (size_t)P * LM;  // [P]
-  double* dinv = beta + P;            // [P]
-  int* nidx = (int*)(dinv + P);       // [n_nbrs rounded up to 4]
+  // lower triangle of the normal equations, packed by rows: entry (i, j <= i) at i (i + 1) / 2 + j -- half the LDS of a
+  // square image (17 KB at k = 64), so twice as many queries share a CU and hide each other's barriers and load latency
+  double* M = (double*)smem;                          // [P (P + 1) / 2]
+  double* beta = M + ((size_t)P * (P + 1) / 2 + 1);   // [P]  right-hand side D^T y, then the solution
+  double* dinv = beta + P;                            // [P]
+  int* nidx = (int*)(dinv + P);                       // [n_nbrs rounded up to 4]
+  auto row = [&](int i) __attribute__((always_inline)) -> double* { return M + ((i * (i + 1)) >> 1); };
   const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
   const int64_t q = blockIdx.x;
   if (q >= n_q) return;
@@ -651,31 +653,48 @@ __global__ __launch_bounds__(64) void grad_fit_lin_kernel(const double* __restri
 #pragma unroll
       for (int b = 0; b < NTT; ++b) acc[a][b] = (f64x4v){0, 0, 0, 0};
     const int nsteps = n4 >> 2;
+    // branch-free (every lane loads: a clamped row, a clamped column, y of that row) so that several neighbour groups can
+    // be in flight at once -- the gather is a chain of dependent DRAM round trips otherwise (20 of them at 80 neighbours)
     auto fragment = [&](int s, double (&fv)[NTT]) __attribute__((always_inline)) {
       const int idx = nidx[4 * s + fg];
+      const int64_t id = idx >= 0 ? idx : 0;
+      const double yv = y[id];
 #pragma unroll
       for (int t = 0; t < NTT; ++t) {
         const int col = 16 * t + fr;
-        double v = 0.0;
-        if (idx >= 0) {
-          if (col < k) v = x[(int64_t)idx * k + col] - x0c[t];
-          else if (col == k) v = 1.0;
-          else if (col == k + 1) v = y[idx];
-        }
-        fv[t] = v;
+        const double xv = x[id * k + (col < k ? col : k - 1)];
+        double v = xv - x0c[t];
+        v = col < k ? v : (col == k ? 1.0 : (col == k + 1 ? yv : 0.0));
+        fv[t] = idx >= 0 ? v : 0.0;
       }
     };
-    // two neighbour groups in flight: the loads of step s + 1 are issued before the MFMAs of step s
-    double fa[NTT], fb[NTT];
-    fragment(0, fa);
-    for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps) fragment(s + 1, fb);
+    auto products = [&](const double (&fv)[NTT]) __attribute__((always_inline)) {
 #pragma unroll
       for (int a = 0; a < NTT; ++a)
 #pragma unroll
-        for (int b = 0; b <= a; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fa[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NTT; ++t) fa[t] = fb[t];
+        for (int b = 0; b <= a; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[a], fv[b], acc[a][b], 0, 0, 0);
+    };
+    // four neighbour groups in flight: the loads of step s + 4 are issued right after the MFMAs of step s
+    double f0[NTT], f1[NTT], f2[NTT], f3[NTT];
+    fragment(0, f0);
+    if (1 < nsteps) fragment(1, f1);
+    if (2 < nsteps) fragment(2, f2);
+    if (3 < nsteps) fragment(3, f3);
+    for (int s = 0; s < nsteps; s += 4) {
+      products(f0);
+      if (s + 4 < nsteps) fragment(s + 4, f0);
+      if (s + 1 < nsteps) {
+        products(f1);
+        if (s + 5 < nsteps) fragment(s + 5, f1);
+      }
+      if (s + 2 < nsteps) {
+        products(f2);
+        if (s + 6 < nsteps) fragment(s + 6, f2);
+      }
+      if (s + 3 < nsteps) {
+        products(f3);
+        if (s + 7 < nsteps) fragment(s + 7, f3);
+      }
     }
     // D layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 reg
 #pragma unroll
@@ -686,20 +705,20 @@ __global__ __launch_bounds__(64) void grad_fit_lin_kernel(const double* __restri
         for (int rg = 0; rg < 4; ++rg) {
           const int i = 16 * a + fg + 4 * rg, j = 16 * b + fr;
           const double v = acc[a][b][rg];
-          if (i < P && j <= i) M[i * LM + j] = v + ((i == j) ? ridge : 0.0);
-          if (i == P && j < P) M[j * LM + P] = v;  // row k + 1 of G = D^T y
+          if (i < P && j <= i) row(i)[j] = v + ((i == j) ? ridge : 0.0);
+          if (i == P && j < P) beta[j] = v;  // row k + 1 of G = D^T y
         }
     __syncthreads();
     if (attempt == 0) {
       double dm = 0.0;
-      for (int i = lane; i < P; i += 64) dm = fmax(dm, M[i * LM + i]);
+      for (int i = lane; i < P; i += 64) dm = fmax(dm, row(i)[i]);
       for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off, 64));
       dmax = dm;
     }
     // ---- Cholesky, left-looking, lane = row (see grad_fit_kernel); eight products in flight per lane ----
     bool ok = true;
     for (int j = 0; j < P; ++j) {
-      const double* rj = M + j * LM;
+      const double* rj = row(j);
       auto dot = [&](const double* ri) __attribute__((always_inline)) -> double {
         double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
         int p2 = 0;
@@ -722,13 +741,13 @@ __global__ __launch_bounds__(64) void grad_fit_lin_kernel(const double* __restri
       rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
       const int i0 = j + 1 + lane, i1 = i0 + 64;   // P <= 65: at most two rows per lane
       double c0 = 0.0, c1 = 0.0;
-      if (i0 < P) c0 = (M[i0 * LM + j] - dot(M + i0 * LM)) * rinv;
-      if (i1 < P) c1 = (M[i1 * LM + j] - dot(M + i1 * LM)) * rinv;
+      if (i0 < P) c0 = (row(i0)[j] - dot(row(i0))) * rinv;
+      if (i1 < P) c1 = (row(i1)[j] - dot(row(i1))) * rinv;
       __syncthreads();  // every read of row j is done
-      if (i0 < P) M[i0 * LM + j] = c0;
-      if (i1 < P) M[i1 * LM + j] = c1;
+      if (i0 < P) row(i0)[j] = c0;
+      if (i1 < P) row(i1)[j] = c1;
       if (lane == 0) {
-        M[j * LM + j] = sjj * rinv;
+        row(j)[j] = sjj * rinv;
         dinv[j] = rinv;
       }
       __syncthreads();
@@ -743,20 +762,18 @@ __global__ __launch_bounds__(64) void grad_fit_lin_kernel(const double* __restri
     __syncthreads();
   }
   if (fl != 2) {
-    for (int r = lane; r < P; r += 64) beta[r] = M[r * LM + P];
-    __syncthreads();
     for (int i = 0; i < P; ++i) {
       const double zi = beta[i] * dinv[i];
       __syncthreads();
       if (lane == 0) beta[i] = zi;
-      for (int r = i + 1 + lane; r < P; r += 64) beta[r] -= M[r * LM + i] * zi;
+      for (int r = i + 1 + lane; r < P; r += 64) beta[r] -= row(r)[i] * zi;
       __syncthreads();
     }
     for (int i = P - 1; i >= 0; --i) {
       const double bi = beta[i] * dinv[i];
       __syncthreads();
       if (lane == 0) beta[i] = bi;
-      for (int r = lane; r < i; r += 64) beta[r] -= M[i * LM + r] * bi;
+      for (int r = lane; r < i; r += 64) beta[r] -= row(i)[r] * bi;
       __syncthreads();
     }
   }
@@ -764,8 +781,8 @@ __global__ __launch_bounds__(64) void grad_fit_lin_kernel(const double* __restri
   if (lane == 0 && status) status[q] = fl;
 }
 inline size_t grad_fit_lin_lds_bytes(int k, int n_nbrs) {
-  const int P = k + 1, LM = (P + 1) | 1;
-  return ((size_t)P * LM + 2 * P) * 8 + (size_t)((n_nbrs + 3) & ~3) * 4 + 64;
+  const int P = k + 1;
+  return ((size_t)P * (P + 1) / 2 + 1 + 2 * P) * 8 + (size_t)((n_nbrs + 3) & ~3) * 4 + 64;
 }
 
 // m_in_lds = false: the normal equations live in global memory (grad_fit_kernel's m_glob)

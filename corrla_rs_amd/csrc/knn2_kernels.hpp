@@ -51,7 +51,9 @@ constexpr float kK2Margin = 2.0e-4f;    // bound on |d^2_filter - d^2| / (|q|^2 
 __host__ __device__ constexpr int k2_chunk_bytes(int s) { return s * 8192; }            // s = 32-dimension MFMA steps
 __host__ __device__ constexpr int k2_stage_bytes(int s) { return k2_chunk_bytes(s) + 256; }  // + 64 f32 norms
 // two stages + one 64-coordinate f64 row per wave (the query whose candidates are being re-checked)
-__host__ __device__ constexpr int k2_lds_bytes(int s) { return 2 * k2_stage_bytes(s) + kK2Waves * 512; }
+constexpr int kK2Stages = 3;            // ring of staged chunks: two in flight behind the one being scanned (with one, every
+                                        // chunk waited for its own DMA: 29 % of the scan at 1e6 points, CORRLA_KNN2_PROF)
+__host__ __device__ constexpr int k2_lds_bytes(int s) { return kK2Stages * k2_stage_bytes(s) + kK2Waves * 512 + 1024; }
 
 struct Knn2Args {
   const __bf16* pb;   // [chunk][s][plane (hi, lo)][tile t of 16 points][lane][8]: B fragments of the centred points
@@ -65,6 +67,8 @@ struct Knn2Args {
   double* list_d;     // [gridDim.x][kK2Q][kK2List]
   int* list_i;        // [gridDim.x][kK2Q][kK2List]
   int* nbr;           // out: [n_q][n_nbrs], nearest first
+  unsigned long long* prof;  // optional (CORRLA_KNN2_PROF): 100 MHz ticks of wave 0 of every workgroup, summed:
+                             // [0] in flushes, [1] waiting for the chunk (DMA + barrier), [2] in all, [3] list merges (batches)
 };
 
 // column means of x (n x k row-major), two stages in fixed order: partial[b][d] = sum over the rows of block b
@@ -181,16 +185,28 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
   int* const li_w = g.list_i + ((int64_t)blockIdx.x * kK2Q + wave * kK2WQ) * kK2List;
   const double inf = __builtin_huge_val();
 
+  // every wave issues the same number of DMA instructions per chunk (DPW: fragments, the norms, dummies into a scratch
+  // KiB), so that a counted s_waitcnt leaves exactly the youngest chunk in flight (loads retire in order)
+  constexpr int DPW = (NDMA + 1 + kK2Waves - 1) / kK2Waves;
+  char* const dma_scratch = smem + kK2Stages * STG + kK2Waves * 512;
   auto stage = [&](int buf, int64_t c) __attribute__((always_inline)) {
     char* st = smem + buf * STG;
     const char* src = (const char*)g.pb + c * (int64_t)k2_chunk_bytes(S);
 #pragma unroll
-    for (int i = wave; i < NDMA; i += kK2Waves) glds16(src + i * 1024 + lane * 16, st + i * 1024);
-    if (wave == (NDMA % kK2Waves))
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.pn + c * kK2Chunk + lane),
-                                       (__attribute__((address_space(3))) void*)(st + k2_chunk_bytes(S)), 4, 0, 0);
+    for (int j = 0; j < DPW; ++j) {
+      const int i = wave + j * kK2Waves;
+      if (i < NDMA)
+        glds16(src + i * 1024 + lane * 16, st + i * 1024);
+      else if (i == NDMA)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.pn + c * kK2Chunk + lane),
+                                         (__attribute__((address_space(3))) void*)(st + k2_chunk_bytes(S)), 4, 0, 0);
+      else
+        glds16((const char*)g.pb + lane * 16, dma_scratch);  // (any readable KiB)
+    }
   };
 
+  unsigned long long t_flush = 0, t_wait = 0, n_batches = 0;
+  const unsigned long long t_begin = g.prof ? wall_clock64() : 0;
   for (int64_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
     const int64_t q0 = tile * kK2Q + wave * kK2WQ;  // this wave's 32 queries: local query qi = 16 mw + (row of tile mw)
     // ---- A fragments: query q0 + 16 mw + fr, dimensions 32 s + 8 fg + j, centred, two bf16 pieces; |q - mean|^2 ----
@@ -254,12 +270,13 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
       l1.i = __hip_atomic_load(li_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // the query's row goes to LDS once (wave-private 512 bytes): the re-check reads it as broadcasts instead of holding
       // it in registers next to the candidate's row
-      double* const qs = (double*)(smem + 2 * STG) + wave * 64;
+      double* const qs = (double*)(smem + kK2Stages * STG) + wave * 64;
       qs[lane] = lane < kdim ? g.xq[q * kdim + lane] : 0.0;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       for (int b0 = 0; b0 < ncand; b0 += 64) {
+        ++n_batches;
         K2Key c;
         c.d = inf;
         c.i = 0x7fffffff;
@@ -350,11 +367,21 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
     };
 
     if (g.nchunks > 0) stage(0, 0);
+    if (g.nchunks > 1) stage(1, 1);
+    int buf = 0;
     for (int64_t c = 0; c < g.nchunks; ++c) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of chunk c has landed
+      const unsigned long long tw0 = g.prof ? wall_clock64() : 0;
+      // this wave's share of chunk c has landed; chunk c + 1 (the youngest DPW loads) may stay in flight.  Stores (the
+      // candidate appends) count in vmcnt too but cannot make the wait pass early: loads retire in order.
+      if (c + 1 < g.nchunks)
+        wait_vmcnt<DPW>();
+      else
+        wait_vmcnt<0>();
       __syncthreads();                                    // chunk c is complete; every wave is done with chunk c - 1
-      if (c + 1 < g.nchunks) stage((int)((c + 1) & 1), c + 1);
-      const char* st = smem + (int)(c & 1) * STG;
+      if (g.prof) t_wait += wall_clock64() - tw0;
+      if (c + 2 < g.nchunks) stage(buf >= 1 ? buf - 1 : kK2Stages - 1, c + 2);  // = (c + 2) % 3: the slot of chunk c - 1
+      const char* st = smem + buf * STG;
+      buf = buf + 1 == kK2Stages ? 0 : buf + 1;
       f32x4 acc[kK2RowTiles][4];
 #pragma unroll
       for (int mw = 0; mw < kK2RowTiles; ++mw)
@@ -417,7 +444,11 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
       const int cmax = max(max(max(cnt_r[0], cnt_r[1]), max(cnt_r[2], cnt_r[3])), max(max(cnt_r[4], cnt_r[5]), max(cnt_r[6], cnt_r[7])));
       // (one call site: the per-query registers above stay registers only if the flush code is inlined once)
       const int least = point ? 1 : (__any(cmax > kK2Cap - kK2Chunk) ? kK2Cap - kK2Chunk + 1 : 0);
-      if (least) flush_wave(least);
+      if (least) {
+        const unsigned long long tf0 = g.prof ? wall_clock64() : 0;
+        flush_wave(least);
+        if (g.prof) t_flush += wall_clock64() - tf0;
+      }
     }
     // ---- results: the first n_nbrs entries of every list, nearest first ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -429,6 +460,12 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
         g.nbr[q * g.n_nbrs + e] = __hip_atomic_load(li_w + qi * kK2List + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();  // the stage buffers are free for the next tile
+  }
+  if (g.prof && threadIdx.x == 0) {
+    atomicAdd(g.prof + 0, t_flush);
+    atomicAdd(g.prof + 1, t_wait);
+    atomicAdd(g.prof + 2, wall_clock64() - t_begin);
+    atomicAdd(g.prof + 3, n_batches);
   }
 }
 
