@@ -52,7 +52,7 @@ CONFIGS = {
     "C5": (1_000_000, 64, 32, 8, 10, "weak", "BASELINE.json configs[4]", "f64"),
 }
 SEED_A, SEED_OMEGA = 20241008, 1
-PEAK_MFMA_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X_MICROARCH.md: dense f32 / f64 matrix peaks
+PEAK_MFMA_TFLOPS = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense f32 / f64 / bf16 matrix peaks
 PEAK_F32_MFMA_TFLOPS = PEAK_MFMA_TFLOPS["f32"]
 PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 CPU_THREADS = 16               # a 1-GPU box's CPU share; OpenBLAS is pinned to this many threads
@@ -287,16 +287,24 @@ def run_c5(args):
     ctx.grad_mat(x, y, 1, n_nbrs, scale=1.0 / np.sqrt(n_pts))
     torch.cuda.synchronize(dev)
     t_grad = time.perf_counter() - t1
-    # dominant kernel: the k-NN scan (f32 MFMA filter): N^2 point pairs x 2 k flops of the distance tile
-    pair_flops = float(n_pts) * n_pts * 2 * kf
-    achieved = pair_flops / t_grad / 1e12
-    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS["f32"], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_MFMA_TFLOPS["f32"], 4), "traffic": None,
-                "traffic_source": "not collected for this configuration",
-                "kernel": "gradient stage = grad_transpose + point_norms + knn_mfma_kernel (f32 MFMA distance filter, exact f64 "
-                          "re-check) + grad_fit_kernel, timed as a whole with the host clock around one untimed extra call",
-                "avg_launch_ms": round(t_grad * 1e3, 2),
-                "algorithmic": f"N^2 = {n_pts}^2 point pairs x {2 * kf} flop (distance tile of k = {kf} dimensions)"}
+    tm = ctx.timings()   # hipEvents the library records on its own stream around the scan and around the fits
+    knn_ms, fit_ms = float(tm["knn_ms"]), float(tm["fit_ms"])
+    # Dominant kernel: the k-NN scan (knn2_kernels.hpp).  Its filter evaluates every (query, point) pair once as a
+    # bf16x3 product on v_mfma_f32_16x16x32_bf16 (hi hi + hi lo + lo hi of the centred coordinates, the dimension padded
+    # to a multiple of 32): algorithmic flops = N * N_q * 2 * k_pad * 3, priced against the dense bf16 MFMA peak.
+    k_pad = -(-kf // 32) * 32
+    pair_flops = float(n_pts) * n_pts * 2 * k_pad * 3
+    achieved = pair_flops / (knn_ms * 1e-3) / 1e12 if knn_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS["bf16"], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_MFMA_TFLOPS["bf16"], 4), "traffic": None,
+                "traffic_source": "not collected for this configuration (the scan re-reads a 0.5 GB bf16 image of the cloud "
+                                  "once per query tile through L2 / LDS-DMA; it is issue-bound, DESIGN.md section 7)",
+                "kernel": "knn2_kernel<2> (+ its prep kernels): exact k-NN, bf16x3 MFMA filter on centred coordinates, every "
+                          "survivor re-checked in f64",
+                "avg_launch_ms": round(knn_ms, 2),
+                "algorithmic": f"N x N_q = {n_pts}^2 point pairs x 2 x {k_pad} flop x 3 bf16 products of the split operands",
+                "pair_evaluations_per_s": round(float(n_pts) * n_pts / (knn_ms * 1e-3), 1) if knn_ms > 0 else None,
+                "fit_kernel_ms": round(fit_ms, 2)}
     from oracle import active_ss_oracle as aso
     from threadpoolctl import threadpool_limits
     threads, avail = host_threads()
@@ -317,7 +325,8 @@ def run_c5(args):
                                f"(RSVD of the {kf} x {n_pts} gradient matrix, rank {rank}, q={q}, p={p}); {CONFIGS['C5'][6]}",
                    "n_samples": n_pts, "n_features": kf, "n_nbrs": n_nbrs, "rank": rank, "parallelism": "single GPU"},
         "roofline": roofline,
-        "phases_ms": {"gradient_stage": round(t_grad * 1e3, 2), "fit_svd_rsvd": round(ms_per_step - t_grad * 1e3, 2)},
+        "phases_ms": {"gradient_stage": round(t_grad * 1e3, 2), "knn_scan": round(knn_ms, 2), "local_fits": round(fit_ms, 2),
+                      "fit_svd_rsvd": round(ms_per_step - t_grad * 1e3, 2)},
         "cpu_baseline": {"value": round(1.0 / t_cpu, 3), "unit": "samples/s", "cores": threads, "kind": "port",
                          "sample": f"oracle/active_ss_oracle.py create_grad_mat (numpy restatement of active_subspaces.rs:66-141,"
                                    f"215-229) on {nq} queries against the same {n_pts}-point cloud: {t_cpu:.3f} s per query on "
@@ -325,7 +334,7 @@ def run_c5(args):
         "accuracy": {"max_rel_dev_of_gradients_vs_oracle_sample": err, "gate": 1e-10, "passed": bool(err <= 1e-10),
                      "n_regularised": int(nreg), "queries_compared": nq},
     }
-    log(f"[bench] C5: step {ms_per_step:.1f} ms (gradient stage {t_grad * 1e3:.1f} ms = {achieved:.1f} TF on the pair tile), "
+    log(f"[bench] C5: step {ms_per_step:.1f} ms (gradient stage {t_grad * 1e3:.1f} ms: scan {knn_ms:.1f} ms = {achieved:.0f} TF bf16, fits {fit_ms:.1f} ms), "
         f"{result['value']:.0f} samples/s; gradients vs oracle {err:.2e}")
     print(json.dumps(result), flush=True)
 
@@ -509,7 +518,7 @@ def main():
                 ceil, ceil_src = measured_f64_ceiling()
                 if ceil:
                     roofline["measured_stream_ceiling"] = {"TFLOPs": ceil, "frac_of_it": round(achieved / ceil, 4), "source": ceil_src,
-                                                           "note": "what a register-only v_mfma_f64_16x16x4_f64 stream sustains on this part"}
+                                                           "note": "best register-only v_mfma_f64_16x16x4_f64 stream on this part (two waves per SIMD; one wave: 60.5)"}
         roofline.update({
             "traffic_unit": f"bytes per launch (algorithmic: {m_loc * n * esz:.4g} A + {n * l * esz:.3g} Omega + {m_loc * l * esz:.3g} out)",
             "traffic_source": traffic_src,

@@ -31,7 +31,7 @@ class Timings(C.Structure):
     _fields_ = [("total_ms", dbl), ("sketch_ms", dbl), ("power_ms", dbl), ("qr_ms", dbl), ("project_ms", dbl),
                 ("small_svd_ms", dbl), ("finalize_ms", dbl), ("qr_passes", i32), ("n_collectives", i32),
                 ("sketch_kernel_ms", dbl), ("host_enqueue_ms", dbl), ("collective_bytes", dbl), ("n_mixed_products", i32),
-                ("reserved_", i32)]
+                ("reserved_", i32), ("knn_ms", dbl), ("fit_ms", dbl)]
 
 
 # symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header

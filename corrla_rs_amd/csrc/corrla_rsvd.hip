@@ -189,6 +189,8 @@ CORRLA_API corrla_status corrla_ctx_get_timings(corrla_ctx* ctx, corrla_timings*
     out->host_enqueue_ms = t.host_enqueue_ms;
     out->n_mixed_products = t.n_mixed_products;
     out->reserved_ = 0;
+    out->knn_ms = t.knn_ms;
+    out->fit_ms = t.fit_ms;
   });
 }
 
@@ -302,6 +304,7 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     if (n_q > 0x7fffffff) throw Error(ST_EINVAL, "too many query points for one launch");
     // Both kernels spend ~n_nbrs ln(n_pts / n_nbrs) list insertions per query; the MFMA distance tile only pays off
     // once the scan itself dominates (measured: 5e4 points 0.10 s VALU / 0.14 s MFMA, 1e5 0.28 / 0.30, 2e5 0.93 / 0.45)
+    dev.event_mark(0);  // corrla_timings.knn_ms / fit_ms: events 0-1 around the scan, 1-2 around the fits
     const int knn_mode = env_int("CORRLA_KNN", 0);  // 1: VALU kernel, 2: f32-MFMA kernel, 3: bf16-filter kernel, 0: by size
     // knn2_kernels.hpp (round 3): bf16x3 MFMA filter + batched bitonic list merges; n_nbrs <= 128.  Small clouds keep the
     // VALU scan (its per-query lists live in LDS and there is too little work to amortise the split of the cloud).
@@ -383,6 +386,7 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
 #undef CORRLA_KNN_LAUNCH
     }
     const int64_t ldgd = host_ptrs ? kf : ldg;
+    dev.event_mark(1);
     // order 1: the MFMA-built normal equations (round 3; CORRLA_FIT=1 keeps the general kernel)
     if (est_order == 1 && env_int("CORRLA_FIT", 0) != 1) {
       const size_t lds_lin = k::grad_fit_lin_lds_bytes(kk, nn);
@@ -415,7 +419,12 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     if (host_ptrs)
       CORRLA_HIP(hipMemcpy2DAsync(g, sizeof(double) * (size_t)ldg, gd, sizeof(double) * (size_t)kf, sizeof(double) * (size_t)kf,
                                   (size_t)n_q, hipMemcpyDeviceToHost, dev.stream));
+    dev.event_mark(2);
     dev.end_call();
+    c->last = Timings();
+    c->last.knn_ms = dev.event_elapsed_ms(0, 1);
+    c->last.fit_ms = dev.event_elapsed_ms(1, 2);
+    c->last.total_ms = c->last.knn_ms + c->last.fit_ms;
     int bad = 0;
     for (int v : hs) bad += v != 0;
     if (n_regularised) *n_regularised = bad;

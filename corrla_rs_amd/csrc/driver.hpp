@@ -121,6 +121,7 @@ struct Timings {
   int qr_passes = 0;
   int n_collectives = 0;        // all-reduces issued by this call on this rank (row-sharded entry points)
   double collective_bytes = 0;  // payload bytes of those all-reduces
+  double knn_ms = 0, fit_ms = 0;  // gradient stage (corrla_grad_mat_*): neighbour scan / local fits
   int n_mixed_products = 0;     // tall products that ran on the bf16-split kernels (RunOpts::mixed_planes)
   // breakdown of qr_ms (only filled when phase profiling is on): Gram GEMM, D2H + analysis, host Cholesky /
   // inverse, H2D + apply GEMM

@@ -178,7 +178,7 @@ class HipDev {
   // ---- memory ----------------------------------------------------------------------------
   void begin_call() {
     CORRLA_HIP(hipSetDevice(device));
-    events_set_[0] = events_set_[1] = false;
+    events_set_[0] = events_set_[1] = events_set_[2] = false;
     n_collectives = 0;
     collective_bytes = 0;
     marks_.clear();
@@ -1515,8 +1515,8 @@ class HipDev {
   std::vector<Chunk> zchunks_;  // zero pool (alloc_zeroed)
   void* zero_page_ = nullptr;
   void* pinned_ = nullptr;  // staging for the small l x l transfers
-  hipEvent_t events_[2] = {nullptr, nullptr};
-  bool events_set_[2] = {false, false};
+  hipEvent_t events_[3] = {nullptr, nullptr, nullptr};
+  bool events_set_[3] = {false, false, false};
   struct PhaseMark {
     hipEvent_t ev;
     double* slot;

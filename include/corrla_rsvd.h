@@ -137,6 +137,8 @@ typedef struct corrla_timings {
   double collective_bytes; /* payload bytes of those all-reduces (n x l factors, l x l Gram matrices, scalars) */
   int32_t n_mixed_products; /* tall products of this call that ran on the bf16-split kernels (CORRLA_SKETCH_BF16X3 / X6) */
   int32_t reserved_;
+  double knn_ms;        /* corrla_grad_mat_*: device time of the neighbour scan (hipEvents around its launches) */
+  double fit_ms;        /* corrla_grad_mat_*: device time of the local least-squares fits; both 0 after any other call */
 } corrla_timings;
 
 /* ---- library / context ------------------------------------------------------------- */
