@@ -493,13 +493,21 @@ def main():
             kern = f"gemm_nn_kernel<{tname},2,{nt_tiles}> + slab_reduce"
             traffic, traffic_src = pmc_traffic()
         elif args.config == "C3":
-            kern = f"gemm_nn_kernel<{tname},2,9> + gemm_nn_kernel<{tname},2,8> (17 column tiles = 9 + 8, two launches)"
-            traffic, traffic_src = pmc_traffic(("gemm_nn_kernel<double, 2, 9", "gemm_nn_kernel<double, 2, 8"),
-                                               r"r\d+_pmc_f64_gemm_summary\.txt$", reduce_substr=None)
+            # f64: eight MFMA waves of one row tile each on the 128-index tile (round 3; CORRLA_F64_WAVES=4: <double, 2, NT>)
+            w8 = os.environ.get("CORRLA_F64_WAVES", "8") != "4"
+            names = ("gemm_nn_kernel<double, 1, 9, false, 8>", "gemm_nn_kernel<double, 1, 8, false, 8>") if w8 else \
+                    ("gemm_nn_kernel<double, 2, 9", "gemm_nn_kernel<double, 2, 8")
+            kern = " + ".join(n_ if n_.endswith(">") else n_ + ">" for n_ in names) + " (17 column tiles = 9 + 8, two launches)"
+            traffic, traffic_src = pmc_traffic(names, r"r\d+_pmc_f64_gemm_summary\.txt$", reduce_substr=None)
         else:
             kern = f"gemm_nn_kernel<{tname},2,{nt_tiles}>"
             traffic, traffic_src = pmc_traffic((f"gemm_nn_kernel<{tname}, 2, {nt_tiles}",), r"r\d+_pmc_c4_gemm_summary\.txt$",
                                                reduce_substr=None)
+            if traffic is not None:
+                # the PMC passes ran on ONE 1/8 row shard (1,250,000 rows, tools/profile_sketch.py c4); the kernel streams its
+                # rows once, so the bytes of this launch scale with the rows this rank holds
+                traffic = traffic * (m_loc / 1_250_000.0)
+                traffic_src += f"; measured on a 1,250,000-row shard, scaled by rows to this rank's {m_loc}"
         steady = {"avg_launch_ms": round(sk_warm_ms, 4), "note": "same launch back-to-back after warm launches (clock ramp)"}
         if args.mixed:
             # the split kernels are no longer bound by the matrix pipe: the roof is the stream of A from HBM

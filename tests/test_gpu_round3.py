@@ -243,6 +243,8 @@ def test_knn2_is_the_default_scan_and_handles_few_queries_many_points(ctx, torch
     xq = x[:1000]
     gm, nreg = ctx.grad_mat(x, y, 1, 48, xq)
     assert nreg == 0 and gm.shape == (k, 1000)
+    tm = ctx.timings()   # corrla_timings after a gradient call: the scan's and the fits' device time, nothing else
+    assert tm["knn_ms"] > 0 and tm["fit_ms"] > 0 and tm["sketch_kernel_ms"] == 0 and tm["n_mixed_products"] == 0
     from oracle import active_ss_oracle as aso
     xs, ys = x.cpu().numpy(), y.cpu().numpy()
     go = aso.create_grad_mat(aso.PolyGradientEstimator(xs, ys, 1, 48), xs[:12])
