@@ -357,8 +357,12 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
         std::fprintf(stderr, "knn2 prof (wave 0 of %lld workgroups, 100 MHz ticks): total %llu, flushes %llu (%.1f %%), chunk waits %llu (%.1f %%), "
                      "%llu merge batches\n", (long long)wgs, h[2], h[0], 100.0 * h[0] / (double)h[2], h[1], 100.0 * h[1] / (double)h[2], h[3]);
       }
-    } else if (knn_mode == 1 || (knn_mode == 0 && n_pts < 131072)) {
+    } else if (knn_mode == 1 || (knn_mode == 0 && n_pts < 131072) ||
+               k::knn_mfma_lds_bytes(kk, nn, 2) > (size_t)160 * 1024) {
+      // (also when the MFMA scan's per-query lists outgrow LDS: n_nbrs > ~400 at k = 64 -- the VALU scan's fit up to the
+      //  interface's 512)
       const size_t lds_knn = k::knn_lds_bytes(kk, nn);
+      if (lds_knn > (size_t)160 * 1024) throw Error(ST_EINVAL, "problem does not fit in LDS");
       const int64_t knn_blocks = (n_q + k::kKnnQueries - 1) / k::kKnnQueries;
       hipLaunchKernelGGL(k::knn_kernel, dim3((unsigned)knn_blocks), dim3(64 * k::kKnnWaves), lds_knn, dev.stream, (const double*)xt,
                          ldt, n_pts, kk, qd, n_q, nn, nbr);

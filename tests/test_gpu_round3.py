@@ -303,3 +303,19 @@ def test_f64_products_with_eight_mfma_waves_are_bitwise_those_of_four(torch, mon
         ref = (a.t() if trans else a) @ rhs
         assert torch.equal(z8, z4), float((z8 - z4).abs().max())
         assert float((z8 - ref).abs().max()) <= 1e-11 * float(ref.abs().max())
+
+
+def test_many_neighbours_on_a_large_cloud_take_the_scan_whose_lists_fit(ctx):
+    """n_nbrs = 480 on 140 000 points: beyond the 128-entry lists of the bf16-filter scan, and the per-query lists of round
+    2's MFMA scan would need 190 KB of LDS -- the call used to end with CORRLA_EINVAL ("does not fit in LDS") although the
+    interface promises n_nbrs <= 512 (found by tools/fuzz_grad.py).  The VALU scan serves it."""
+    from oracle import active_ss_oracle as aso
+    rng = np.random.default_rng(480)
+    n, k, n_nbrs, nq = 140_000, 12, 480, 40
+    x = rng.standard_normal((n, k))
+    y = np.cos(x @ rng.standard_normal(k) * 0.2) + 0.1 * (x ** 2).sum(axis=1)
+    xq = x[rng.permutation(n)[:nq]]
+    g, nreg = ctx.grad_mat(x, y, 1, n_nbrs, xq)
+    assert nreg == 0
+    go = aso.create_grad_mat(aso.PolyGradientEstimator(x, y, 1, n_nbrs), xq[:6])
+    assert np.max(np.abs(g[:, :6] - go)) <= 1e-9 * np.abs(go).max()
