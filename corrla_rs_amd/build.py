@@ -46,7 +46,7 @@ def build_product(force=False, verbose=False):
     # "Cannot find Symbol" at the first launch on the GPU box).  So: compile a private copy of the sources, and put the
     # result in place with one rename -- a snapshot of the tree taken during a build sees the old library or the new one.
     import tempfile
-    with tempfile.TemporaryDirectory(prefix="corrla_build_") as tmp:
+    with tempfile.TemporaryDirectory(prefix=".corrla_build_", dir=LIB_DIR) as tmp:  # inside the tree: nothing is written elsewhere
         csrc = os.path.join(tmp, "corrla_rs_amd", "csrc")  # same relative layout: the sources include "../../include/..."
         shutil.copytree(CSRC, csrc)
         shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))

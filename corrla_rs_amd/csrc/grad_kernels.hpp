@@ -449,12 +449,6 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
   }
   for (int r = lane; r < n_nbrs; r += 64) yn[r] = y[nidx[r]];
   __syncthreads();
-  auto design = [&](int r, int c) -> double {
-    const int a = pa[c], b = pb[c];
-    if (a < 0) return 1.0;
-    const double va = xn[r * k + a];
-    return b < 0 ? va : va * xn[r * k + b];
-  };
   // sum_r v(r, i) v(r, j)  (j == P: the right-hand side sum_r v(r, i) y_r).  The column descriptors are hoisted out
   // of the loop over the neighbours, so its LDS reads are independent of one another and pipeline.
   auto gram_entry = [&](int i, int j) -> double {

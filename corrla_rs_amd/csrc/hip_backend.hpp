@@ -1208,7 +1208,6 @@ class HipDev {
     // quadratic convergence: a sweep that starts below sqrt(eps) ends below tol -- except for clustered singular
     // values, whose W / sigma factor the driver re-orthonormalises afterwards (see small_svd_mc)
     const T tol_early = env_int("CORRLA_JACOBI_STRICT", 0) ? tol : (T)std::sqrt(eps);
-    const T floor2 = (T)((double)l * eps * eps);  // squared norm of a numerically zero column (see the kernel)
     const bool v_lds = lds2 <= kLdsMax;
     const size_t lds = v_lds ? lds2 : lds1;
     // ring kernel: columns resident in registers (l <= 144)

@@ -306,7 +306,6 @@ template <class T, int PIPE>
 __device__ __forceinline__ typename MT<T>::acc_t wy_kdot(const T* acol, const T* bcol, int k0, int rows, int g,
                                                          typename MT<T>::acc_t w0) {
   typedef MT<T> M;
-  typedef typename M::acc_t acc_t;
   constexpr int kWyPipe = PIPE;  // (shadows the default depth)
   auto load = [&](int kk, T(&av)[kWyPipe], T(&bv)[kWyPipe]) {
     if (kk + 4 * kWyPipe <= rows) {
