@@ -31,6 +31,8 @@ pub const CORRLA_QR_HOUSEHOLDER: u32 = 0x8;
 pub const CORRLA_SEED_EXPLICIT: u32 = 0x10;
 pub const CORRLA_POWER_FUSED: u32 = 0x20;
 pub const CORRLA_SHARD_COLS: u32 = 0x40;
+pub const CORRLA_SKETCH_BF16X3: u32 = 0x80; // opt-in: range finder on the bf16-split kernels (f32 inputs only)
+pub const CORRLA_SKETCH_BF16X6: u32 = 0x100;
 
 extern "C" {
     fn corrla_ctx_create(device: c_int, out: *mut *mut c_void) -> c_int;

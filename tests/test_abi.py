@@ -171,3 +171,20 @@ def test_every_kernel_the_host_code_launches_exists_in_the_device_code_object():
     have = set(re.findall(r"\s(_Z\S+)", dev))
     missing = sorted(s for s in stubs if s not in have or (s + ".kd") not in have)
     assert not missing, "kernels without device code: %s" % missing[:5]
+
+
+def test_rust_shim_mirrors_the_header_constants_and_prototypes():
+    """integration/rust cannot be compiled in this image (no Rust toolchain), so at least its text is held against the
+    header: every flag it declares has the header's value, every flag of the header is declared, and every extern "C"
+    function it names is a prototype of include/corrla_rsvd.h."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rs = open(os.path.join(root, "integration", "rust", "src", "lib.rs")).read()
+    hdr = open(os.path.join(root, "include", "corrla_rsvd.h")).read()
+    rs_flags = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"pub const (CORRLA_[A-Z0-9_]+): u32 = (0x[0-9a-fA-F]+);", rs)}
+    h_flags = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"#define (CORRLA_[A-Z0-9_]+) (0x[0-9a-fA-F]+)u\b", hdr)}
+    assert rs_flags, "no flags found in the shim"
+    assert rs_flags == {k: v for k, v in h_flags.items() if k in rs_flags}
+    assert set(h_flags) <= set(rs_flags), sorted(set(h_flags) - set(rs_flags))
+    fns = set(re.findall(r"\bfn (corrla_[a-z0-9_]+)\(", rs))
+    assert fns and all(re.search(r"\b%s\(" % f, hdr) for f in fns), [f for f in fns if not re.search(r"\b%s\(" % f, hdr)]
