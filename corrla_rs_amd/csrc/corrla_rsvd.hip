@@ -313,7 +313,7 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
       const int S = kk <= 32 ? 1 : 2;
       const int64_t nchunks = (n_pts + k::kK2Chunk - 1) / k::kK2Chunk;
       __bf16* pb = (__bf16*)dev.alloc_bytes((size_t)nchunks * (size_t)k::k2_chunk_bytes(S));
-      float* pnf = (float*)dev.alloc_bytes((size_t)nchunks * k::kK2Chunk * sizeof(float));
+      float* pnf = (float*)dev.alloc_bytes((size_t)nchunks * k::kK2Chunk * 4 * sizeof(float));  // -c_p, four copies per point
       double* mean = (double*)dev.alloc_bytes(64 * sizeof(double));
       const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n_pts + 4095) / 4096));
       const int64_t rpb = (n_pts + nb - 1) / nb;

@@ -12,7 +12,8 @@
 //    as small as the data allow): 24 MFMAs of 16 cycles per chunk and wave instead of 64 of 32.  The support points are
 //    split ONCE (knn2_prep_kernel) into MFMA B-fragment order, so a chunk is 16 KiB of linear LDS-DMA and every fragment
 //    read is one conflict-free ds_read_b128.  A pair passes when  d^2_filter - margin (|q|^2 + |p|^2) < tau_q  (tau_q = the
-//    query's current n-th exact distance; margin 2e-4 bounds every rounding of the filter) -- conservative, never exact.
+//    query's current n-th exact distance; margin 2e-4 bounds every rounding of the filter) -- conservative, never exact;
+//    the point's share of that test rides in as the MFMA's C operand, so the test is one compare per pair.
 //  * SURVIVORS are only appended (4-byte index, ballot + popcount, no sorting) to a per-query candidate buffer.
 //  * FLUSHES are batched and ALIGNED: after chunks 1, 2, 4, 8, ... (the expected number of survivors per query between
 //    chunk c and 2c is n ln 2) every wave empties the buffers of its 32 queries at the same time -- the waves of a
@@ -49,15 +50,16 @@ constexpr int kK2Chunk = 64;            // support points per chunk
 constexpr float kK2Margin = 2.0e-4f;    // bound on |d^2_filter - d^2| / (|q|^2 + |p|^2), see the header
 
 __host__ __device__ constexpr int k2_chunk_bytes(int s) { return s * 8192; }            // s = 32-dimension MFMA steps
-__host__ __device__ constexpr int k2_stage_bytes(int s) { return k2_chunk_bytes(s) + 256; }  // + 64 f32 norms
+__host__ __device__ constexpr int k2_stage_bytes(int s) { return k2_chunk_bytes(s) + 1024; }  // + 64 x 4 f32: -c_p, replicated
 // two stages + one 64-coordinate f64 row per wave (the query whose candidates are being re-checked)
-constexpr int kK2Stages = 3;            // ring of staged chunks: two in flight behind the one being scanned (with one, every
+constexpr int kK2Stages = 4;            // ring of staged chunks: three in flight behind the one being scanned (with one, every
                                         // chunk waited for its own DMA: 29 % of the scan at 1e6 points, CORRLA_KNN2_PROF)
 __host__ __device__ constexpr int k2_lds_bytes(int s) { return kK2Stages * k2_stage_bytes(s) + kK2Waves * 512 + 1024; }
 
 struct Knn2Args {
   const __bf16* pb;   // [chunk][s][plane (hi, lo)][tile t of 16 points][lane][8]: B fragments of the centred points
-  const float* pn;    // [chunk][64]: |x_p - mean|^2 rounded to f32; +inf for the padding points of the last chunk
+  const float* pn;    // [chunk][64][4]: -c_p = -(1 - margin) |x_p - mean|^2 / 2 in f32, four copies (one 16-byte MFMA C operand
+                      // per point column); -inf for the padding points of the last chunk
   const double* x;    // support points, row-major n_pts x k
   const double* xq;   // queries, row-major n_q x k
   const double* mean; // [k]
@@ -117,16 +119,16 @@ __global__ __launch_bounds__(256) void knn2_prep_kernel(const double* __restrict
   }
   if (tid < kK2Chunk) {
     const int64_t p = c * kK2Chunk + tid;
-    float out = __builtin_huge_valf();
+    float out = -__builtin_huge_valf();
     if (p < n_pts) {
       double s2 = 0.0;
       for (int d = 0; d < k; ++d) {
         const double df = x[p * k + d] - mean[d];
         s2 += df * df;
       }
-      out = (float)s2;
+      out = -(0.5f * (1.0f - kK2Margin)) * (float)s2;
     }
-    pn[c * kK2Chunk + tid] = out;
+    *(f32x4*)(pn + (c * kK2Chunk + tid) * 4) = (f32x4){out, out, out, out};
   }
 }
 
@@ -171,6 +173,110 @@ __device__ __forceinline__ void k2_sort(K2Key& a, int lane) {
   }
 }
 
+// Per-lane state of a wave's 32 queries, element e = 4 (row tile) + r for the query at accumulator register r of the lane's
+// group.  (The flush was tried OUT OF LINE, to keep its ~100 registers of sort / merge / re-check state out of the scan
+// loop's allocation: the values live across the call then lived in scratch for the whole loop -- worse.  What works is
+// the loop structure of the kernel: an inner scan loop without any flush code, the flush between two runs of it.)
+struct K2WaveState {
+  float qn[8], cq[8];
+  int cnt[8];
+};
+// Flush every query of this wave whose buffer holds at least `least` candidates: batch-merge them into the query's sorted
+// list (64 at a time, lane = candidate: exact f64 distance, bitonic sort, two-stage bitonic merge) and refresh its filter
+// threshold.  qs: the wave's 512-byte LDS row.
+// (the kernel's argument block is passed field by field: taking its address moves the whole block to scratch)
+__device__ __forceinline__ void k2_flush_wave(const double* __restrict__ x, const double* __restrict__ xq, int kdim, int n_nbrs,
+                                                       K2WaveState* st, int least, int64_t q0, int* cand_w, double* ld_w,
+                                                       int* li_w, double* qs, unsigned long long* n_batches) {
+  const int lane = threadIdx.x & 63, fg = lane >> 4;
+  const double inf = __builtin_huge_val();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's candidate stores have left it
+#pragma unroll 1
+  for (int qi = 0; qi < kK2WQ; ++qi) {
+    const int gq = (qi >> 2) & 3, e = 4 * (qi >> 4) + (qi & 3);  // lane group and state element of the query
+    const int ncand = __shfl(st->cnt[e], 16 * gq, 64);
+    if (ncand < least || ncand == 0) continue;  // uniform
+    const int64_t q = q0 + qi;
+    K2Key l0, l1;
+    l0.d = __hip_atomic_load(ld_w + qi * kK2List + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    l0.i = __hip_atomic_load(li_w + qi * kK2List + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    l1.d = __hip_atomic_load(ld_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    l1.i = __hip_atomic_load(li_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the query's row goes to LDS once (wave-private): the re-check reads it as broadcasts instead of holding it in
+    // registers next to the candidate's row
+    qs[lane] = lane < kdim ? xq[q * kdim + lane] : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int b0 = 0; b0 < ncand; b0 += 64) {
+      if (n_batches) ++*n_batches;
+      K2Key c;
+      c.d = inf;
+      c.i = 0x7fffffff;
+      if (b0 + lane < ncand) {
+        c.i = __hip_atomic_load(cand_w + qi * kK2Cap + b0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double* pp = x + (int64_t)c.i * kdim;
+        double s0 = 0.0, s1 = 0.0;
+        int d = 0;
+        // 16 coordinates per memory round trip (a plain loop waits for every pair: 32 dependent round trips per batch at
+        // k = 64); same summation order: even coordinates into s0, odd ones into s1, ascending
+        for (; d + 16 <= kdim; d += 16) {
+          double pv[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) pv[j] = pp[d + j];
+#pragma unroll
+          for (int j = 0; j < 16; j += 2) {
+            const double a0 = pv[j] - qs[d + j], a1 = pv[j + 1] - qs[d + j + 1];
+            s0 += a0 * a0;
+            s1 += a1 * a1;
+          }
+        }
+        for (; d + 1 < kdim; d += 2) {
+          const double a0 = pp[d] - qs[d], a1 = pp[d + 1] - qs[d + 1];
+          s0 += a0 * a0;
+          s1 += a1 * a1;
+        }
+        if (d < kdim) {
+          const double a0 = pp[d] - qs[d];
+          s0 += a0 * a0;
+        }
+        c.d = s0 + s1;
+        if (!(c.d == c.d)) c.d = inf;  // a non-finite distance sorts last, like numpy's argsort of a NaN
+      }
+      k2_sort(c, lane);
+      // the 64 smallest of L1 and the candidates (ascending with descending: the elementwise minimum is bitonic) ...
+      K2Key m = k2_shfl(c, 63 - lane);
+      if (k2_less(l1, m)) m = l1;
+      k2_bitonic_merge(m, lane);
+      // ... then L0 against them: minima = the new L0, maxima = the new L1
+      const K2Key rm = k2_shfl(m, 63 - lane);
+      K2Key lo = l0, hi = rm;
+      if (k2_less(rm, l0)) {
+        lo = rm;
+        hi = l0;
+      }
+      k2_bitonic_merge(lo, lane);
+      k2_bitonic_merge(hi, lane);
+      l0 = lo;
+      l1 = hi;
+    }
+    __hip_atomic_store(ld_w + qi * kK2List + lane, l0.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(li_w + qi * kK2List + lane, l0.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ld_w + qi * kK2List + 64 + lane, l1.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(li_w + qi * kK2List + 64 + lane, l1.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nn = n_nbrs;
+    const double tau = nn <= 64 ? __shfl(l0.d, nn - 1, 64) : __shfl(l1.d, nn - 65, 64);
+    // the filter compares in f32: round the threshold UP (never below the exact n-th distance); the few ulps the f32
+    // evaluation of cq loses are part of the margin
+    float tf = (float)tau;
+    if ((double)tf < tau) tf = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, tf) + 1u);  // tau >= 0: next float up
+    if (fg == gq) {
+      st->cq[e] = tf < __builtin_huge_valf() ? 0.5f * ((1.0f - kK2Margin) * st->qn[e] - tf) : -__builtin_huge_valf();
+      st->cnt[e] = 0;
+    }
+  }
+}
+
 template <int S>
 __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -198,8 +304,7 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
       if (i < NDMA)
         glds16(src + i * 1024 + lane * 16, st + i * 1024);
       else if (i == NDMA)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.pn + c * kK2Chunk + lane),
-                                         (__attribute__((address_space(3))) void*)(st + k2_chunk_bytes(S)), 4, 0, 0);
+        glds16((const char*)(g.pn + c * (kK2Chunk * 4)) + lane * 16, st + k2_chunk_bytes(S));
       else
         glds16((const char*)g.pb + lane * 16, dma_scratch);  // (any readable KiB)
     }
@@ -239,11 +344,11 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
     // (ext-vector registers with constant indices: plain arrays captured by the flush lambdas ended up in scratch)
     typedef int i32x8 __attribute__((ext_vector_type(8)));
     typedef float f32x8 __attribute__((ext_vector_type(8)));
-    // The filter per pair:  d^2_filter - margin (qn + pn) < tau   <=>   q.p > cq + cp  with
-    //   cq = ((1 - margin) qn - tau) / 2  per query (changes at a flush),  cp = (1 - margin) pn / 2  per point:
-    // one add and one compare per pair, the compare writing the lane mask the slow path needs anyway.
+    // The filter per pair:  d^2_filter - margin (qn + pn) < tau   <=>   q.p - cp > cq  with
+    //   cq = ((1 - margin) qn - tau) / 2  per query (changes at a flush),  cp = (1 - margin) pn / 2  per point, which the
+    // accumulators start from (see the chunk loop): one compare per pair, writing the lane mask the slow path needs anyway.
     // cq = -inf while the list is not full (everything passes), +inf for the padding queries of the last tile
-    // (nothing passes); padding points carry pn = +inf, hence cp = +inf.
+    // (nothing passes); padding points carry -cp = -inf.
     f32x8 qn_r, cq_r;
     i32x8 cnt_r;
 #pragma unroll
@@ -260,153 +365,68 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
       __hip_atomic_store(li_w + e, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // batch-merge the candidates of local query qi (uniform) into its list; returns the new n-th distance
-    auto flush_query = [&](int qi, int ncand) __attribute__((always_inline)) -> double {
-      const int64_t q = q0 + qi;
-      K2Key l0, l1;
-      l0.d = __hip_atomic_load(ld_w + qi * kK2List + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      l0.i = __hip_atomic_load(li_w + qi * kK2List + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      l1.d = __hip_atomic_load(ld_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      l1.i = __hip_atomic_load(li_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // the query's row goes to LDS once (wave-private 512 bytes): the re-check reads it as broadcasts instead of holding
-      // it in registers next to the candidate's row
-      double* const qs = (double*)(smem + kK2Stages * STG) + wave * 64;
-      qs[lane] = lane < kdim ? g.xq[q * kdim + lane] : 0.0;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (int b0 = 0; b0 < ncand; b0 += 64) {
-        ++n_batches;
-        K2Key c;
-        c.d = inf;
-        c.i = 0x7fffffff;
-        if (b0 + lane < ncand) {
-          c.i = __hip_atomic_load(cand_w + qi * kK2Cap + b0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const double* pp = g.x + (int64_t)c.i * kdim;
-          double s0 = 0.0, s1 = 0.0;
-          int d = 0;
-          // 16 coordinates per memory round trip (the plain loop below waits for every pair: 32 dependent round trips
-          // per batch at k = 64, which was most of the scan's time); same summation order: even coordinates into s0, odd
-          // ones into s1, ascending
-          for (; d + 16 <= kdim; d += 16) {
-            double pv[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) pv[j] = pp[d + j];
-#pragma unroll
-            for (int j = 0; j < 16; j += 2) {
-              const double a0 = pv[j] - qs[d + j], a1 = pv[j + 1] - qs[d + j + 1];
-              s0 += a0 * a0;
-              s1 += a1 * a1;
-            }
-          }
-          for (; d + 1 < kdim; d += 2) {
-            const double a0 = pp[d] - qs[d], a1 = pp[d + 1] - qs[d + 1];
-            s0 += a0 * a0;
-            s1 += a1 * a1;
-          }
-          if (d < kdim) {
-            const double a0 = pp[d] - qs[d];
-            s0 += a0 * a0;
-          }
-          c.d = s0 + s1;
-          if (!(c.d == c.d)) c.d = inf;  // a non-finite distance sorts last, like numpy's argsort of a NaN
-        }
-        k2_sort(c, lane);
-        // the 64 smallest of L1 and the candidates (ascending with descending: the elementwise minimum is bitonic) ...
-        K2Key m = k2_shfl(c, 63 - lane);
-        if (k2_less(l1, m)) m = l1;
-        k2_bitonic_merge(m, lane);
-        // ... then L0 against them: minima = the new L0, maxima = the new L1
-        const K2Key rm = k2_shfl(m, 63 - lane);
-        K2Key lo = l0, hi = rm;
-        if (k2_less(rm, l0)) {
-          lo = rm;
-          hi = l0;
-        }
-        k2_bitonic_merge(lo, lane);
-        k2_bitonic_merge(hi, lane);
-        l0 = lo;
-        l1 = hi;
-      }
-      __hip_atomic_store(ld_w + qi * kK2List + lane, l0.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(li_w + qi * kK2List + lane, l0.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(ld_w + qi * kK2List + 64 + lane, l1.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(li_w + qi * kK2List + 64 + lane, l1.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int nn = g.n_nbrs;
-      return nn <= 64 ? __shfl(l0.d, nn - 1, 64) : __shfl(l1.d, nn - 65, 64);
-    };
-    // flush every query of this wave whose buffer holds at least `least` candidates
-    auto flush_wave = [&](int least) __attribute__((always_inline)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's candidate stores have left it
-#pragma unroll 1
-      for (int qi = 0; qi < kK2WQ; ++qi) {
-        const int gq = (qi >> 2) & 3, e = 4 * (qi >> 4) + (qi & 3);  // lane group and state element of the query
-        int mine = cnt_r[0];
-        float qn_q = qn_r[0];
-#pragma unroll
-        for (int u = 1; u < 8; ++u) {
-          mine = e == u ? cnt_r[u] : mine;
-          qn_q = e == u ? qn_r[u] : qn_q;
-        }
-        const int nc = __shfl(mine, 16 * gq, 64);
-        if (nc < least || nc == 0) continue;  // uniform
-        const double tau = flush_query(qi, nc);
-        // the filter compares in f32: round the threshold UP (never below the exact n-th distance); the few ulps the
-        // f32 evaluation of cq loses are part of the margin
-        float tf = (float)tau;
-        if ((double)tf < tau) tf = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, tf) + 1u);  // tau >= 0: next float up
-        if (fg == gq) {
-          const float cq = tf < __builtin_huge_valf() ? 0.5f * ((1.0f - kK2Margin) * qn_q - tf) : -__builtin_huge_valf();
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            cq_r[u] = e == u ? cq : cq_r[u];
-            cnt_r[u] = e == u ? 0 : cnt_r[u];
-          }
-        }
-      }
-    };
-
     if (g.nchunks > 0) stage(0, 0);
     if (g.nchunks > 1) stage(1, 1);
+    if (g.nchunks > 2) stage(2, 2);
     int buf = 0;
-    for (int64_t c = 0; c < g.nchunks; ++c) {
+    // Two loop levels: the INNER loop scans chunks and holds no flush code at all (so the register allocator keeps the
+    // scan's values in registers and parks what only the flush needs outside it); it ends when a flush is due -- an aligned
+    // flush point, or a buffer that could overflow in the next chunk -- and the flush runs between two runs of it.
+    int64_t c = 0;
+    while (c < g.nchunks) {
+    int least = 0;
+#pragma unroll 1
+    for (; c < g.nchunks && least == 0; ++c) {
       const unsigned long long tw0 = g.prof ? wall_clock64() : 0;
-      // this wave's share of chunk c has landed; chunk c + 1 (the youngest DPW loads) may stay in flight.  Stores (the
-      // candidate appends) count in vmcnt too but cannot make the wait pass early: loads retire in order.
-      if (c + 1 < g.nchunks)
+      // This wave's share of chunk c has landed; chunks c + 1 and c + 2 (the youngest 2 DPW loads) may stay in flight.
+      // The DMA of chunk c + 3 is issued at the END of the iteration, after the candidate appends: stores count in vmcnt
+      // too, and appends issued behind a DMA made the counted wait cover that DMA as well (one chunk of prefetch lost).
+      // Appends in between can only make the wait longer, never let it pass early: loads retire in order.
+      if (c + 2 < g.nchunks)
+        wait_vmcnt<2 * DPW>();
+      else if (c + 1 < g.nchunks)
         wait_vmcnt<DPW>();
       else
         wait_vmcnt<0>();
       __syncthreads();                                    // chunk c is complete; every wave is done with chunk c - 1
       if (g.prof) t_wait += wall_clock64() - tw0;
-      if (c + 2 < g.nchunks) stage(buf >= 1 ? buf - 1 : kK2Stages - 1, c + 2);  // = (c + 2) % 3: the slot of chunk c - 1
       const char* st = smem + buf * STG;
+      const int buf_prev = buf >= 1 ? buf - 1 : kK2Stages - 1;  // the slot of chunk c - 1 = that of chunk c + 3
       buf = buf + 1 == kK2Stages ? 0 : buf + 1;
+      // The accumulators start from -c_p (the C operand of the first MFMA of every tile: one 16-byte read per point column,
+      // shared by both row tiles), so that the filter test is ONE compare per pair:  q.p - c_p > c_q.  Padding points carry
+      // -inf and never pass (-inf > c_q is false for every c_q, -inf included).
       f32x4 acc[kK2RowTiles][4];
 #pragma unroll
-      for (int mw = 0; mw < kK2RowTiles; ++mw)
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 ncp = *(const f32x4*)(st + k2_chunk_bytes(S) + (16 * t + fr) * 16);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[mw][t] = (f32x4){0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < S; ++s)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const bf16x8 bh = *(const bf16x8*)(st + ((s * 2 + 0) * 4 + t) * 1024 + lane * 16);
-          const bf16x8 bl = *(const bf16x8*)(st + ((s * 2 + 1) * 4 + t) * 1024 + lane * 16);
+        for (int mw = 0; mw < kK2RowTiles; ++mw) acc[mw][t] = ncp;
+      }
+      // The fragments of step (s, t + 1) are read under the MFMAs of step (s, t): inline-asm ds_reads one step ahead, retired
+      // by hand-counted waits (hip_kernels.hpp: hipcc otherwise issues one of the two reads late and waits for it at once,
+      // and a sched_group_barrier sequence lands one read off).
+      {
+        const unsigned fa = lds_addr(st) + (unsigned)lane * 16u;
+        bf16x8 fh[2], fl[2];
+        lds_read_b128<0>(fh[0], fa);
+        lds_read_b128<4 * 1024>(fl[0], fa);
+        static_for<0, S * 4>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, s_ = i >> 2, t = i & 3, cur = i & 1, nxt = cur ^ 1;
+          if constexpr (i + 1 < S * 4) {
+            constexpr int s2 = (i + 1) >> 2, t2 = (i + 1) & 3;
+            lds_read_b128<((s2 * 2 + 0) * 4 + t2) * 1024>(fh[nxt], fa);
+            lds_read_b128<((s2 * 2 + 1) * 4 + t2) * 1024>(fl[nxt], fa);
+          }
+          lds_wait<(i + 1 < S * 4) ? 2 : 0>(fh[cur]);
+          lds_tie(fl[cur]);
 #pragma unroll
           for (int mw = 0; mw < kK2RowTiles; ++mw) {
-            acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mw][s], bh, acc[mw][t], 0, 0, 0);
-            acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mw][s], bl, acc[mw][t], 0, 0, 0);
-            acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mw][s], bh, acc[mw][t], 0, 0, 0);
+            acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mw][s_], fh[cur], acc[mw][t], 0, 0, 0);
+            acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mw][s_], fl[cur], acc[mw][t], 0, 0, 0);
+            acc[mw][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mw][s_], fh[cur], acc[mw][t], 0, 0, 0);
           }
-        }
-      float cp[4];
-      unsigned long long vm[4];  // lanes whose point of column tile t exists (padding points of the last chunk: pn = +inf)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float pnv = *(const float*)(st + k2_chunk_bytes(S) + (16 * t + fr) * 4);
-        cp[t] = (0.5f * (1.0f - kK2Margin)) * pnv;
-        vm[t] = __ballot(pnv < __builtin_huge_valf());
+        });
       }
       const int base = (int)(c * kK2Chunk);
 #pragma unroll
@@ -417,9 +437,8 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            // negated comparison: a NaN goes through to the exact re-check; cq + cp = +inf never passes (inf - inf = NaN
-            // only where cq = -inf meets the cp = +inf of a padding point, which vm drops)
-            hm[t][r] = __ballot(!(acc[mw][t][r] <= cq_r[4 * mw + r] + cp[t])) & vm[t];
+            // negated comparison: a NaN (a non-finite point or query) goes through to the exact re-check
+            hm[t][r] = __ballot(!(acc[mw][t][r] <= cq_r[4 * mw + r]));
             any |= hm[t][r];
           }
         if (any != 0) {  // uniform
@@ -437,16 +456,30 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
             }
         }
       }
+      if (c + 3 < g.nchunks) stage(buf_prev, c + 3);
       // aligned flush points: after chunks 1, 2, 4, 8, ... and the last one; in between only a buffer that could
       // overflow in the next chunk (64 more candidates) is flushed
       const int64_t done = c + 1;
       const bool point = (done & (done - 1)) == 0 || done == g.nchunks;
       const int cmax = max(max(max(cnt_r[0], cnt_r[1]), max(cnt_r[2], cnt_r[3])), max(max(cnt_r[4], cnt_r[5]), max(cnt_r[6], cnt_r[7])));
-      // (one call site: the per-query registers above stay registers only if the flush code is inlined once)
-      const int least = point ? 1 : (__any(cmax > kK2Cap - kK2Chunk) ? kK2Cap - kK2Chunk + 1 : 0);
+      least = point ? 1 : (__any(cmax > kK2Cap - kK2Chunk) ? kK2Cap - kK2Chunk + 1 : 0);
+    }
       if (least) {
         const unsigned long long tf0 = g.prof ? wall_clock64() : 0;
-        flush_wave(least);
+        K2WaveState stv;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          stv.qn[u] = qn_r[u];
+          stv.cq[u] = cq_r[u];
+          stv.cnt[u] = cnt_r[u];
+        }
+        k2_flush_wave(g.x, g.xq, kdim, g.n_nbrs, &stv, least, q0, cand_w, ld_w, li_w,
+                      (double*)(smem + kK2Stages * STG) + wave * 64, g.prof ? &n_batches : nullptr);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          cq_r[u] = stv.cq[u];
+          cnt_r[u] = stv.cnt[u];
+        }
         if (g.prof) t_flush += wall_clock64() - tf0;
       }
     }
