@@ -431,19 +431,21 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
       const int base = (int)(c * kK2Chunk);
 #pragma unroll
       for (int mw = 0; mw < kK2RowTiles; ++mw) {
-        unsigned long long hm[4][4];
-        unsigned long long any = 0;
+        // survivors are sparse (~2 per wave and chunk once the lists are full): the masks are OR-ed per column tile, so
+        // that a chunk with one survivor costs ~10 scalar tests instead of one (taken) branch per (tile, register)
+        unsigned long long hm[4][4], at[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
+          for (int r = 0; r < 4; ++r)
             // negated comparison: a NaN (a non-finite point or query) goes through to the exact re-check
             hm[t][r] = __ballot(!(acc[mw][t][r] <= cq_r[4 * mw + r]));
-            any |= hm[t][r];
-          }
-        if (any != 0) {  // uniform
+          at[t] = (hm[t][0] | hm[t][1]) | (hm[t][2] | hm[t][3]);
+        }
+        if (((at[0] | at[1]) | (at[2] | at[3])) != 0) {  // uniform
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+          for (int t = 0; t < 4; ++t) {
+            if (at[t] == 0) continue;  // uniform
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const unsigned long long m = hm[t][r];
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
               if (h && slot < kK2Cap) cand_w[(16 * mw + 4 * fg + r) * kK2Cap + slot] = base + 16 * t + fr;
               cnt_r[4 * mw + r] += __popc(gm);
             }
+          }
         }
       }
       if (c + 3 < g.nchunks) stage(buf_prev, c + 3);
