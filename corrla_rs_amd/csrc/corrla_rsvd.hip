@@ -395,9 +395,15 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
     if (est_order == 1 && env_int("CORRLA_FIT", 0) != 1) {
       const size_t lds_lin = k::grad_fit_lin_lds_bytes(kk, nn);
       const int ntt = (kk + 2 + 15) / 16;
+      const k::FitRowTab rtab = k::grad_fit_lin_row_table(kk + 1);
+      unsigned long long* fprof = nullptr;
+      if (env_int("CORRLA_KNN2_PROF", 0)) {
+        fprof = (unsigned long long*)dev.alloc_bytes(4 * sizeof(unsigned long long));
+        CORRLA_HIP(hipMemsetAsync(fprof, 0, 4 * sizeof(unsigned long long), dev.stream));
+      }
 #define CORRLA_FIT_LAUNCH(N_)                                                                                               \
   hipLaunchKernelGGL((k::grad_fit_lin_kernel<N_>), dim3((unsigned)n_q), dim3(64), lds_lin, dev.stream, xd, yd, kk, qd, n_q, \
-                     (const int*)nbr, nn, out_scale, gd, ldgd, status)
+                     (const int*)nbr, nn, out_scale, gd, ldgd, status, fprof, rtab)
       switch (ntt) {
         case 1: CORRLA_FIT_LAUNCH(1); break;
         case 2: CORRLA_FIT_LAUNCH(2); break;
@@ -406,6 +412,15 @@ static corrla_status grad_mat_c(corrla_ctx* ctx, bool host_ptrs, const double* x
         default: CORRLA_FIT_LAUNCH(5); break;
       }
 #undef CORRLA_FIT_LAUNCH
+      if (fprof) {  // diagnostic only: synchronises
+        unsigned long long h[4];
+        CORRLA_HIP(hipMemcpyAsync(h, fprof, sizeof(h), hipMemcpyDeviceToHost, dev.stream));
+        CORRLA_HIP(hipStreamSynchronize(dev.stream));
+        const double tot = (double)(h[0] + h[1] + h[2]);
+        std::fprintf(stderr, "fit prof (%llu queries, 100 MHz ticks per query): gather + normal equations %.0f (%.0f %%), Cholesky %.0f (%.0f %%), "
+                     "solves %.0f (%.0f %%)\n", h[3], h[0] / (double)h[3], 100.0 * h[0] / tot, h[1] / (double)h[3], 100.0 * h[1] / tot,
+                     h[2] / (double)h[3], 100.0 * h[2] / tot);
+      }
     } else if (m_in_lds) {
       hipLaunchKernelGGL(k::grad_fit_kernel, dim3((unsigned)n_q), dim3(64), lds_fit, dev.stream, xd, yd, kk, qd, n_q, (const int*)nbr,
                          nn, est_order, out_scale, gd, ldgd, status, (double*)nullptr, (int64_t)0);

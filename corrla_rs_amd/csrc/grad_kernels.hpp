@@ -612,21 +612,65 @@ __global__ __launch_bounds__(64) void grad_fit_kernel(const double* __restrict__
 //  * LDS holds the packed lower triangle of the (k + 1) x (k + 1) system and its right-hand side only (17 KB at k = 64:
 //    eight queries per CU), factorised left-looking with eight products in flight per lane, solved column-oriented.
 // NTT = 16-column tiles of the design including the constant and y: ceil((k + 2) / 16).
+// Rows of the packed lower triangle of grad_fit_lin_kernel (rows 0 .. P; row P = the right-hand side): row i holds columns
+// 0 .. i in an even number of doubles, so every row starts on a 16-byte LDS slot; the rows are stored in a PERMUTED order
+// chosen so that row i starts at a slot congruent to i modulo 16.  Lane r owns row r, and the 16 lanes a ds_read_b128 is
+// serviced for together have distinct lane numbers modulo 16, so their reads of one column fall into 16 different slots of
+// the 256-byte bank line: conflict-free (in index order the starts are m (m + 1) or (m + 1)^2 slots, which take 4 - 8
+// residues: 4-way conflicts on every read, 12 % of the kernel's LDS cycles).  The greedy below always finds a row of the
+// residue it needs while rows of every residue are left (no padding at P = 65; 2 % at P = 50).
+struct FitRowTab {
+  unsigned short off[68];  // start of row i in doubles
+  unsigned short total;    // doubles in all
+};
+inline FitRowTab grad_fit_lin_row_table(int P) {
+  FitRowTab t{};
+  bool placed[68] = {};
+  int end = 0;  // in 16-byte slots
+  for (int n = 0; n <= P; ++n) {
+    int pick = -1, pad = 0;
+    for (pad = 0; pad < 16 && pick < 0; ++pad) {
+      const int res = (end + pad) & 15;
+      for (int r = P; r >= 0; --r)  // the longest unplaced row of that residue
+        if (!placed[r] && (r & 15) == res) {
+          pick = r;
+          break;
+        }
+      if (pick >= 0) break;
+    }
+    placed[pick] = true;
+    t.off[pick] = (unsigned short)(2 * (end + pad));
+    end += pad + ((pick + 2) >> 1);
+  }
+  t.total = (unsigned short)(2 * end);
+  return t;
+}
 template <int NTT>
 __global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __restrict__ x, const double* __restrict__ y, int k,
                                                           const double* __restrict__ xq, int64_t n_q,
                                                           const int* __restrict__ nbr, int n_nbrs, double out_scale, double* g,
-                                                          int64_t ldg, int* status) {
+                                                          int64_t ldg, int* status, unsigned long long* prof, FitRowTab tab) {
   typedef double f64x4v __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int P = k + 1;             // unknowns: k slopes and the constant
-  // lower triangle of the normal equations, packed by rows: entry (i, j <= i) at i (i + 1) / 2 + j -- half the LDS of a
-  // square image (17 KB at k = 64), so twice as many queries share a CU and hide each other's barriers and load latency
-  double* M = (double*)smem;                          // [P (P + 1) / 2]
-  double* beta = M + ((size_t)P * (P + 1) / 2 + 1);   // [P]  right-hand side D^T y, then the solution
+  // lower triangle of the AUGMENTED normal equations [G b; b^T .] (P + 1 rows: row P is the right-hand side b = D^T y),
+  // packed by rows of even length (16-byte aligned rows: the dot products read two doubles per LDS instruction) -- half
+  // the LDS of a square image (18 KB at k = 64), so several queries share a CU and hide each other's barriers and loads
+  double* M = (double*)smem;                          // [tab.total]
+  double* beta = M + tab.total;                       // [P]  the solution
   double* dinv = beta + P;                            // [P]
   int* nidx = (int*)(dinv + P);                       // [n_nbrs rounded up to 4]
-  auto row = [&](int i) __attribute__((always_inline)) -> double* { return M + ((i * (i + 1)) >> 1); };
+  // row starts: a lane keeps those of its own rows (lane, 64 + lane) in registers -- a pivot row's start is a readlane
+  // away (a per-pivot load from the argument block cost more than the bank conflicts the table removes) -- and a copy in
+  // LDS serves the per-lane lookups of the store after the Gram products
+  unsigned short* offl = (unsigned short*)(nidx + ((n_nbrs + 3) & ~3));  // [128]
+  const int myoff0 = tab.off[threadIdx.x & 63], myoff1 = (threadIdx.x & 63) + 64 <= P ? tab.off[(threadIdx.x & 63) + 64] : 0;
+  offl[threadIdx.x & 63] = (unsigned short)myoff0;
+  offl[64 + (threadIdx.x & 63)] = (unsigned short)myoff1;
+  auto row = [&](int i) __attribute__((always_inline)) -> double* { return M + offl[i]; };            // any i (LDS lookup)
+  auto row_u = [&](int i) __attribute__((always_inline)) -> double* {                                  // uniform i
+    return M + (i < 64 ? __builtin_amdgcn_readlane(myoff0, i) : __builtin_amdgcn_readlane(myoff1, i - 64));
+  };
   const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
   const int64_t q = blockIdx.x;
   if (q >= n_q) return;
@@ -639,6 +683,9 @@ __global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __res
   __syncthreads();
   int fl = 0;
   double ridge = 0.0, dmax = 0.0;
+  // optional (CORRLA_KNN2_PROF): 100 MHz ticks per phase, summed over the queries: [0] gather + normal equations,
+  // [1] Cholesky, [2] triangular solves, [3] queries
+  unsigned long long tp0 = prof ? wall_clock64() : 0, tp1 = 0, tp2 = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     // ---- G = D^T D over the lower-triangle tiles, D = [x - x0, 1, y] (rows = neighbours) ----
     f64x4v acc[NTT][NTT];
@@ -700,7 +747,7 @@ __global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __res
           const int i = 16 * a + fg + 4 * rg, j = 16 * b + fr;
           const double v = acc[a][b][rg];
           if (i < P && j <= i) row(i)[j] = v + ((i == j) ? ridge : 0.0);
-          if (i == P && j < P) beta[j] = v;  // row k + 1 of G = D^T y
+          if (i == P && j < P) row(P)[j] = v;  // row k + 1 of G = D^T y
         }
     __syncthreads();
     if (attempt == 0) {
@@ -709,42 +756,66 @@ __global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __res
       for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off, 64));
       dmax = dm;
     }
-    // ---- Cholesky, left-looking, lane = row (see grad_fit_kernel); eight products in flight per lane ----
+    // ---- Cholesky of the augmented system, left-looking, FIXED row ownership: lane r keeps rows r and 64 + r of the
+    // P + 1 <= 66 rows.  Per pivot j a lane computes ONE dot product (its row against row j: broadcast reads) and updates
+    // its running diagonal  G_rr - sum_p L_rp^2  in a register, from which pivot r is read when its turn comes (readlane:
+    // no LDS round trip, and the 64 copies of the diagonal's dot product that the floating ownership computed are gone);
+    // row P is the right-hand side, so its factor row is the forward-solved z = L^-1 b and only the back substitution is
+    // left.  One barrier per pivot.  (CORRLA_KNN2_PROF on the first version: Cholesky 64 % of the kernel, 12 % of its LDS
+    // cycles bank conflicts.)
+    if (prof && attempt == 0) tp1 = wall_clock64();
+    const int nrows = P + 1;
+    const int r0 = lane, r1 = 64 + lane;
+    double* const row0 = M + myoff0;
+    double* const row1 = M + myoff1;
+    double dg0 = r0 < P ? row0[r0] : 0.0, dg1 = r1 < P ? row1[r1] : 0.0;
+    auto bcast = [&](double v, int src) __attribute__((always_inline)) -> double {  // src uniform
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+      return __hiloint2double(hi, lo);
+    };
+    typedef double f64x2v __attribute__((ext_vector_type(2)));
     bool ok = true;
     for (int j = 0; j < P; ++j) {
-      const double* rj = row(j);
-      auto dot = [&](const double* ri) __attribute__((always_inline)) -> double {
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-        int p2 = 0;
-        for (; p2 + 7 < j; p2 += 8) {
-          t0 += ri[p2] * rj[p2] + ri[p2 + 4] * rj[p2 + 4];
-          t1 += ri[p2 + 1] * rj[p2 + 1] + ri[p2 + 5] * rj[p2 + 5];
-          t2 += ri[p2 + 2] * rj[p2 + 2] + ri[p2 + 6] * rj[p2 + 6];
-          t3 += ri[p2 + 3] * rj[p2 + 3] + ri[p2 + 7] * rj[p2 + 7];
-        }
-        for (; p2 < j; ++p2) t0 += ri[p2] * rj[p2];
-        return (t0 + t1) + (t2 + t3);
-      };
-      const double sjj = rj[j] - dot(rj);
+      const double sjj = j < 64 ? bcast(dg0, j) : bcast(dg1, j - 64);
       if (!(sjj > 1e-13 * dmax)) {
         ok = false;
-        break;  // uniform: every lane reads the same row
+        break;  // uniform
       }
       double rinv = __builtin_amdgcn_rsq(sjj);
       rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
       rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
-      const int i0 = j + 1 + lane, i1 = i0 + 64;   // P <= 65: at most two rows per lane
-      double c0 = 0.0, c1 = 0.0;
-      if (i0 < P) c0 = (row(i0)[j] - dot(row(i0))) * rinv;
-      if (i1 < P) c1 = (row(i1)[j] - dot(row(i1))) * rinv;
-      __syncthreads();  // every read of row j is done
-      if (i0 < P) row(i0)[j] = c0;
-      if (i1 < P) row(i1)[j] = c1;
-      if (lane == 0) {
-        row(j)[j] = sjj * rinv;
+      double* const rj = row_u(j);
+      auto dot = [&](const double* ri) __attribute__((always_inline)) -> double {
+        f64x2v t0 = {0.0, 0.0}, t1 = {0.0, 0.0}, t2 = {0.0, 0.0}, t3 = {0.0, 0.0};
+        int p2 = 0;
+        for (; p2 + 7 < j; p2 += 8) {
+          t0 += *(const f64x2v*)(ri + p2) * *(const f64x2v*)(rj + p2);
+          t1 += *(const f64x2v*)(ri + p2 + 2) * *(const f64x2v*)(rj + p2 + 2);
+          t2 += *(const f64x2v*)(ri + p2 + 4) * *(const f64x2v*)(rj + p2 + 4);
+          t3 += *(const f64x2v*)(ri + p2 + 6) * *(const f64x2v*)(rj + p2 + 6);
+        }
+        for (; p2 + 1 < j; p2 += 2) t0 += *(const f64x2v*)(ri + p2) * *(const f64x2v*)(rj + p2);
+        double tail = 0.0;
+        if (p2 < j) tail = ri[p2] * rj[p2];
+        const f64x2v tt = (t0 + t1) + (t2 + t3);
+        return (tt[0] + tt[1]) + tail;
+      };
+      const bool a0 = r0 > j && r0 < nrows, a1 = r1 > j && r1 < nrows;
+      if (a0) {
+        const double c = (row0[j] - dot(row0)) * rinv;
+        row0[j] = c;
+        dg0 -= c * c;
+      }
+      if (a1) {
+        const double c = (row1[j] - dot(row1)) * rinv;
+        row1[j] = c;
+        dg1 -= c * c;
+      }
+      if (lane == (j & 63)) {  // the owner of row j
+        rj[j] = sjj * rinv;
         dinv[j] = rinv;
       }
-      __syncthreads();
+      __syncthreads();  // column j of the factor is in LDS before pivot j + 1 reads row j + 1 up to it
     }
     if (ok) break;
     if (attempt == 1) {
@@ -755,28 +826,32 @@ __global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __res
     ridge = 1e-10 * dmax;
     __syncthreads();
   }
+  if (prof) tp2 = wall_clock64();
   if (fl != 2) {
-    for (int i = 0; i < P; ++i) {
-      const double zi = beta[i] * dinv[i];
-      __syncthreads();
-      if (lane == 0) beta[i] = zi;
-      for (int r = i + 1 + lane; r < P; r += 64) beta[r] -= row(r)[i] * zi;
-      __syncthreads();
-    }
+    for (int r = lane; r < P; r += 64) beta[r] = row_u(P)[r];  // z = L^-1 b, from the factorisation
+    __syncthreads();
     for (int i = P - 1; i >= 0; --i) {
       const double bi = beta[i] * dinv[i];
       __syncthreads();
       if (lane == 0) beta[i] = bi;
-      for (int r = lane; r < i; r += 64) beta[r] -= row(i)[r] * bi;
+      const double* rowi = row_u(i);
+      for (int r = lane; r < i; r += 64) beta[r] -= rowi[r] * bi;
       __syncthreads();
     }
   }
   for (int m = lane; m < k; m += 64) g[q * ldg + m] = out_scale * (fl != 2 ? beta[m] : 0.0);
   if (lane == 0 && status) status[q] = fl;
+  if (prof && lane == 0) {
+    const unsigned long long tp3 = wall_clock64();
+    atomicAdd(prof + 0, tp1 - tp0);
+    atomicAdd(prof + 1, tp2 - tp1);
+    atomicAdd(prof + 2, tp3 - tp2);
+    atomicAdd(prof + 3, 1ull);
+  }
 }
 inline size_t grad_fit_lin_lds_bytes(int k, int n_nbrs) {
   const int P = k + 1;
-  return ((size_t)P * (P + 1) / 2 + 1 + 2 * P) * 8 + (size_t)((n_nbrs + 3) & ~3) * 4 + 64;
+  return ((size_t)grad_fit_lin_row_table(P).total + 2 * P) * 8 + (size_t)((n_nbrs + 3) & ~3) * 4 + 128 * 2 + 64;
 }
 
 // m_in_lds = false: the normal equations live in global memory (grad_fit_kernel's m_glob)

@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence of a round into gpurun_out/prof_$TAG (run on the MI355X box from the repo root):
 #   kernel-trace + stats of the default bench, one-step timelines (C2, C4 shard, C3), PMC passes on the tall GEMMs
 #   (f32 C2 sketch, f64 C3 sketch; counters in separate passes, never combined with other trace domains).
-# Usage: bash tools/collect_profiles.sh r03 [what...]   what: bench tl_c2 tl_c4 tl_c3 pmc_f32 pmc_f64 (default: these) pmc_c4 pmc_x6 pmc_x3 pmc_c4_x6
+# Usage: bash tools/collect_profiles.sh r03 [what...]   what: bench tl_c2 tl_c4 tl_c3 pmc_f32 pmc_f64 (default: these) pmc_c4 pmc_x6 pmc_x3 pmc_c4_x6 pmc_as
 set -u
 TAG=${1:-r02}; shift || true
 WHAT=${*:-bench tl_c2 tl_c4 tl_c3 pmc_f32 pmc_f64}
@@ -43,6 +43,19 @@ pmc() {  # $1 = f32|f64|c4 [$2 = bf16x6|bf16x3 -> summary pmc_mixed_<mode>_...]
     python3 $REPO/tools/summarize_pmc.py $(find $OUT/pmc_${tag}_$name -name '*counter_collection.csv' | head -1) split_planes >> $sum 2>&1
   done
 }
+pmc_as() {  # gradient stage at 1e6 x 64: the k-NN scan and the fit kernel
+  local sum=$OUT/pmc_active_ss_summary.txt; : > $sum
+  for pass in "sq:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+              "lds:SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS" \
+              "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+    local name=${pass%%:*}; local ctrs=${pass#*:}
+    rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc_as_$name -o $name -- python3 $REPO/tools/bench_active_ss.py 1000000 > $OUT/pmc_as_$name.log 2>&1
+    echo "## pass pmc_$name" >> $sum
+    python3 $REPO/tools/summarize_pmc.py $(find $OUT/pmc_as_$name -name '*counter_collection.csv' | head -1) knn2_kernel >> $sum 2>&1
+    python3 $REPO/tools/summarize_pmc.py $(find $OUT/pmc_as_$name -name '*counter_collection.csv' | head -1) grad_fit >> $sum 2>&1
+  done
+}
+has pmc_as && pmc_as
 has pmc_f32 && pmc f32
 has pmc_f64 && pmc f64
 has pmc_c4 && pmc c4
