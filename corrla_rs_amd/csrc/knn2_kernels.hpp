@@ -138,40 +138,87 @@ struct K2Key {
   int i;
 };
 __device__ __forceinline__ bool k2_less(const K2Key& a, const K2Key& b) { return a.d < b.d || (a.d == b.d && a.i < b.i); }
-__device__ __forceinline__ K2Key k2_shfl_xor(const K2Key& a, int m) {
+// Lane exchanges of the sort / merge networks without the LDS crossbar: DPP inside a row of 16 lanes (quad permutes, row
+// mirrors; lane ^ 4 and lane ^ 8 as two mirrors), gfx950's v_permlane16_swap / v_permlane32_swap across rows.  A network
+// stage on ds_bpermute (what __shfl_xor compiles to) waits ~130 cycles for the crossbar; these are register moves.
+typedef unsigned k2_u32x2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ int k2_dpp(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+// value of lane ^ M (M one of 1, 2, 3, 4, 7, 8, 15, 16, 31, 32, 63)
+template <int M>
+__device__ __forceinline__ int k2_xchg(int v, int lane) {
+  if constexpr (M == 1) return k2_dpp<0xB1>(v);        // quad_perm [1, 0, 3, 2]
+  else if constexpr (M == 2) return k2_dpp<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  else if constexpr (M == 3) return k2_dpp<0x1B>(v);   // quad_perm [3, 2, 1, 0]
+  else if constexpr (M == 7) return k2_dpp<0x141>(v);  // row_half_mirror
+  else if constexpr (M == 15) return k2_dpp<0x140>(v); // row_mirror
+  else if constexpr (M == 4) return k2_dpp<0x1B>(k2_dpp<0x141>(v));   // 7 ^ 3
+  else if constexpr (M == 8) return k2_dpp<0x141>(k2_dpp<0x140>(v));  // 15 ^ 7
+  else if constexpr (M == 16) {
+    // v_permlane16_swap: odd rows of the first operand <-> even rows of the second
+    const k2_u32x2 r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((lane & 16) ? r[0] : r[1]);
+  } else if constexpr (M == 32) {
+    // v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second
+    const k2_u32x2 r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((lane & 32) ? r[0] : r[1]);
+  } else if constexpr (M == 31) return k2_xchg<16>(k2_dpp<0x140>(v), lane);
+  else {
+    static_assert(M == 63, "unsupported lane exchange");
+    return k2_xchg<32>(k2_xchg<16>(k2_dpp<0x140>(v), lane), lane);
+  }
+}
+template <int M>
+__device__ __forceinline__ K2Key k2_xchg_key(const K2Key& a, int lane) {
   K2Key r;
-  r.d = __shfl_xor(a.d, m, 64);
-  r.i = __shfl_xor(a.i, m, 64);
+  r.d = __hiloint2double(k2_xchg<M>(__double2hiint(a.d), lane), k2_xchg<M>(__double2loint(a.d), lane));
+  r.i = k2_xchg<M>(a.i, lane);
   return r;
 }
-__device__ __forceinline__ K2Key k2_shfl(const K2Key& a, int src) {
-  K2Key r;
-  r.d = __shfl(a.d, src, 64);
-  r.i = __shfl(a.i, src, 64);
-  return r;
+// one compare-exchange stage with partner lane ^ M; `lower` lanes keep the smaller key
+template <int M>
+__device__ __forceinline__ void k2_stage(K2Key& a, int lane, bool lower) {
+  const K2Key o = k2_xchg_key<M>(a, lane);
+  if (k2_less(o, a) == lower) a = o;
 }
 // a bitonic sequence over the lanes -> ascending
 __device__ __forceinline__ void k2_bitonic_merge(K2Key& a, int lane) {
-#pragma unroll
-  for (int j = 32; j >= 1; j >>= 1) {
-    const K2Key o = k2_shfl_xor(a, j);
-    const bool lower = (lane & j) == 0;
-    if (k2_less(o, a) == lower) a = o;  // lower lane keeps the smaller key, upper lane the larger
-  }
+  k2_stage<32>(a, lane, (lane & 32) == 0);
+  k2_stage<16>(a, lane, (lane & 16) == 0);
+  k2_stage<8>(a, lane, (lane & 8) == 0);
+  k2_stage<4>(a, lane, (lane & 4) == 0);
+  k2_stage<2>(a, lane, (lane & 2) == 0);
+  k2_stage<1>(a, lane, (lane & 1) == 0);
 }
-// any sequence -> ascending
+// any sequence -> ascending: for every block size 2, 4, .. 64 a "flip" stage (partner = the mirror position inside the
+// block) followed by the half-cleaners lane ^ (block / 4) .. lane ^ 1
 __device__ __forceinline__ void k2_sort(K2Key& a, int lane) {
-#pragma unroll
-  for (int kk = 2; kk <= 64; kk <<= 1) {
-#pragma unroll
-    for (int j = kk >> 1; j >= 1; j >>= 1) {
-      const K2Key o = k2_shfl_xor(a, j);
-      const bool up = (lane & kk) == 0 || kk == 64;
-      const bool lower = (lane & j) == 0;
-      if (k2_less(o, a) == (lower == up)) a = o;
-    }
-  }
+  k2_stage<1>(a, lane, (lane & 1) == 0);
+  k2_stage<3>(a, lane, (lane & 2) == 0);
+  k2_stage<1>(a, lane, (lane & 1) == 0);
+  k2_stage<7>(a, lane, (lane & 4) == 0);
+  k2_stage<2>(a, lane, (lane & 2) == 0);
+  k2_stage<1>(a, lane, (lane & 1) == 0);
+  k2_stage<15>(a, lane, (lane & 8) == 0);
+  k2_stage<4>(a, lane, (lane & 4) == 0);
+  k2_stage<2>(a, lane, (lane & 2) == 0);
+  k2_stage<1>(a, lane, (lane & 1) == 0);
+  k2_stage<31>(a, lane, (lane & 16) == 0);
+  k2_stage<8>(a, lane, (lane & 8) == 0);
+  k2_stage<4>(a, lane, (lane & 4) == 0);
+  k2_stage<2>(a, lane, (lane & 2) == 0);
+  k2_stage<1>(a, lane, (lane & 1) == 0);
+  k2_stage<63>(a, lane, (lane & 32) == 0);
+  k2_stage<16>(a, lane, (lane & 16) == 0);
+  k2_stage<8>(a, lane, (lane & 8) == 0);
+  k2_stage<4>(a, lane, (lane & 4) == 0);
+  k2_stage<2>(a, lane, (lane & 2) == 0);
+  k2_stage<1>(a, lane, (lane & 1) == 0);
 }
+// the keys in reverse lane order
+__device__ __forceinline__ K2Key k2_reverse(const K2Key& a, int lane) { return k2_xchg_key<63>(a, lane); }
 
 // Per-lane state of a wave's 32 queries, element e = 4 (row tile) + r for the query at accumulator register r of the lane's
 // group.  (The flush was tried OUT OF LINE, to keep its ~100 registers of sort / merge / re-check state out of the scan
@@ -203,7 +250,8 @@ __device__ __forceinline__ void k2_flush_wave(const double* __restrict__ x, cons
     l1.d = __hip_atomic_load(ld_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     l1.i = __hip_atomic_load(li_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the query's row goes to LDS once (wave-private): the re-check reads it as broadcasts instead of holding it in
-    // registers next to the candidate's row
+    // registers next to the candidate's row.  (Loading list, row and the first candidate indices one query ahead was
+    // tried: the flush got no faster and the scan loop's register allocation suffered -- 435 -> 532 ms.)
     qs[lane] = lane < kdim ? xq[q * kdim + lane] : 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -218,8 +266,19 @@ __device__ __forceinline__ void k2_flush_wave(const double* __restrict__ x, cons
         const double* pp = x + (int64_t)c.i * kdim;
         double s0 = 0.0, s1 = 0.0;
         int d = 0;
-        // 16 coordinates per memory round trip (a plain loop waits for every pair: 32 dependent round trips per batch at
-        // k = 64); same summation order: even coordinates into s0, odd ones into s1, ascending
+        // 32, then 16 coordinates per memory round trip (a plain loop waits for every pair: 32 dependent round trips per
+        // batch at k = 64); same summation order: even coordinates into s0, odd ones into s1, ascending
+        for (; d + 32 <= kdim; d += 32) {
+          double pv[32];
+#pragma unroll
+          for (int j = 0; j < 32; ++j) pv[j] = pp[d + j];
+#pragma unroll
+          for (int j = 0; j < 32; j += 2) {
+            const double a0 = pv[j] - qs[d + j], a1 = pv[j + 1] - qs[d + j + 1];
+            s0 += a0 * a0;
+            s1 += a1 * a1;
+          }
+        }
         for (; d + 16 <= kdim; d += 16) {
           double pv[16];
 #pragma unroll
@@ -245,11 +304,11 @@ __device__ __forceinline__ void k2_flush_wave(const double* __restrict__ x, cons
       }
       k2_sort(c, lane);
       // the 64 smallest of L1 and the candidates (ascending with descending: the elementwise minimum is bitonic) ...
-      K2Key m = k2_shfl(c, 63 - lane);
+      K2Key m = k2_reverse(c, lane);
       if (k2_less(l1, m)) m = l1;
       k2_bitonic_merge(m, lane);
       // ... then L0 against them: minima = the new L0, maxima = the new L1
-      const K2Key rm = k2_shfl(m, 63 - lane);
+      const K2Key rm = k2_reverse(m, lane);
       K2Key lo = l0, hi = rm;
       if (k2_less(rm, l0)) {
         lo = rm;
@@ -265,7 +324,9 @@ __device__ __forceinline__ void k2_flush_wave(const double* __restrict__ x, cons
     __hip_atomic_store(ld_w + qi * kK2List + 64 + lane, l1.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(li_w + qi * kK2List + 64 + lane, l1.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nn = n_nbrs;
-    const double tau = nn <= 64 ? __shfl(l0.d, nn - 1, 64) : __shfl(l1.d, nn - 65, 64);
+    const double tsel = nn <= 64 ? l0.d : l1.d;  // (nn is uniform: readlane)
+    const int tl = nn <= 64 ? nn - 1 : nn - 65;
+    const double tau = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tsel), tl), __builtin_amdgcn_readlane(__double2loint(tsel), tl));
     // the filter compares in f32: round the threshold UP (never below the exact n-th distance); the few ulps the f32
     // evaluation of cq loses are part of the margin
     float tf = (float)tau;

@@ -188,3 +188,41 @@ def test_rust_shim_mirrors_the_header_constants_and_prototypes():
     assert set(h_flags) <= set(rs_flags), sorted(set(h_flags) - set(rs_flags))
     fns = set(re.findall(r"\bfn (corrla_[a-z0-9_]+)\(", rs))
     assert fns and all(re.search(r"\b%s\(" % f, hdr) for f in fns), [f for f in fns if not re.search(r"\b%s\(" % f, hdr)]
+
+
+def test_knn2_scan_loop_keeps_clear_of_scratch_and_of_uncounted_waits():
+    """Performance guard on the ISA of knn2_kernel<2> (the scan of BASELINE config 5).  Twice in round 3 a change to the
+    rare flush code made hipcc keep DMA source pointers or query fragments of the SCAN loop in scratch -- every chunk then
+    re-loaded them behind an `s_waitcnt vmcnt(0)` that also emptied the DMA ring (0.44 -> 0.53 s, results unchanged, so no
+    parity test notices).  From the chunk barrier through the MFMAs and the append path to the DMA issue that ends the
+    iteration there must be no scratch access and no `s_waitcnt vmcnt(0)`."""
+    import re
+    import subprocess
+    from corrla_rs_amd import build as B
+    lib = B.build_product()
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    data = open(lib, "rb").read()
+    text = ""
+    for mm in re.finditer(b"\x7fELF", data):
+        i = mm.start()
+        if data[i + 18: i + 20] == b"\xe0\x00":      # e_machine = EM_AMDGPU
+            tmp = os.path.join(os.path.dirname(lib), "_device_code_object.tmp")
+            with open(tmp, "wb") as f:
+                f.write(data[i:])
+            text += subprocess.run([objdump, "-d", "--mcpu=gfx950", "--disassemble-symbols=_ZN6corrla1k11knn2_kernelILi2EEEvNS0_8Knn2ArgsE", tmp],
+                                   capture_output=True, text=True).stdout
+            os.remove(tmp)
+    lines = [l for l in text.splitlines() if "\t" in l]
+    mfma = [i for i, l in enumerate(lines) if "v_mfma_f32_16x16x32_bf16" in l]
+    assert len(mfma) >= 48, "knn2_kernel<2> not found in the device code (%d MFMAs)" % len(mfma)
+    barriers = [i for i, l in enumerate(lines) if "s_barrier" in l and i < mfma[0]]
+    assert barriers, "no barrier in front of the scan loop's MFMAs"
+    # ... and on through the append path to the DMA issue of chunk c + 3 that ends the iteration
+    dma = [i for i, l in enumerate(lines) if "global_load_lds" in l and mfma[-1] < i < mfma[-1] + 700]
+    assert dma, "no DMA issue behind the scan loop's MFMAs"
+    loop = lines[barriers[-1]: dma[-1] + 1]
+    assert len(loop) < 1200, "unexpected loop shape (%d instructions in the scan iteration)" % len(loop)
+    bad = [l.strip() for l in loop if "scratch_" in l or re.search(r"s_waitcnt\s+vmcnt\(0\)\s*$", l)]
+    assert not bad, bad[:4]
