@@ -37,8 +37,8 @@
 namespace corrla {
 namespace k {
 
-constexpr int kK2Waves = 12;            // scanning waves per workgroup = 3 per SIMD (168 VGPRs: at 4 per SIMD the query fragments spill);
-                                        // rate, ~25 GB/s per CU, bounded the scan at 8)
+constexpr int kK2Waves = 12;            // scanning waves per workgroup = 3 per SIMD (168 VGPRs: at 4 per SIMD the query fragments spill;
+                                        // 8 waves x 4 row tiles at 256 VGPRs measured 446 vs 436 ms at 1e6 points)
 constexpr int kK2RowTiles = 2;          // 16-query MFMA row tiles per wave: every B fragment read from LDS serves both
                                         // (with one, the 16 waves' fragment reads -- 256 KiB per chunk and CU at 128 B/clk
                                         // -- outweighed the MFMAs)
@@ -225,8 +225,8 @@ __device__ __forceinline__ K2Key k2_reverse(const K2Key& a, int lane) { return k
 // loop's allocation: the values live across the call then lived in scratch for the whole loop -- worse.  What works is
 // the loop structure of the kernel: an inner scan loop without any flush code, the flush between two runs of it.)
 struct K2WaveState {
-  float qn[8], cq[8];
-  int cnt[8];
+  float qn[4 * kK2RowTiles], cq[4 * kK2RowTiles];
+  int cnt[4 * kK2RowTiles];
 };
 // Flush every query of this wave whose buffer holds at least `least` candidates: batch-merge them into the query's sorted
 // list (64 at a time, lane = candidate: exact f64 distance, bitonic sort, two-stage bitonic merge) and refresh its filter
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
     }
     // D layout of row tile mw: column (point) = lane & 15, row (query) = 16 mw + 4 fg + r; per-query state at [4 mw + r]
     // (ext-vector registers with constant indices: plain arrays captured by the flush lambdas ended up in scratch)
-    typedef int i32x8 __attribute__((ext_vector_type(8)));
-    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    typedef int i32x8 __attribute__((ext_vector_type(4 * kK2RowTiles)));
+    typedef float f32x8 __attribute__((ext_vector_type(4 * kK2RowTiles)));
     // The filter per pair:  d^2_filter - margin (qn + pn) < tau   <=>   q.p - cp > cq  with
     //   cq = ((1 - margin) qn - tau) / 2  per query (changes at a flush),  cp = (1 - margin) pn / 2  per point, which the
     // accumulators start from (see the chunk loop): one compare per pair, writing the lane mask the slow path needs anyway.
@@ -525,14 +525,16 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
       // overflow in the next chunk (64 more candidates) is flushed
       const int64_t done = c + 1;
       const bool point = (done & (done - 1)) == 0 || done == g.nchunks;
-      const int cmax = max(max(max(cnt_r[0], cnt_r[1]), max(cnt_r[2], cnt_r[3])), max(max(cnt_r[4], cnt_r[5]), max(cnt_r[6], cnt_r[7])));
+      int cmax = cnt_r[0];
+#pragma unroll
+      for (int u = 1; u < 4 * kK2RowTiles; ++u) cmax = max(cmax, cnt_r[u]);
       least = point ? 1 : (__any(cmax > kK2Cap - kK2Chunk) ? kK2Cap - kK2Chunk + 1 : 0);
     }
       if (least) {
         const unsigned long long tf0 = g.prof ? wall_clock64() : 0;
         K2WaveState stv;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4 * kK2RowTiles; ++u) {
           stv.qn[u] = qn_r[u];
           stv.cq[u] = cq_r[u];
           stv.cnt[u] = cnt_r[u];
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(64 * kK2Waves, kK2Waves / 4) void knn2_kernel(Knn2A
         k2_flush_wave(g.x, g.xq, kdim, g.n_nbrs, &stv, least, q0, cand_w, ld_w, li_w,
                       (double*)(smem + kK2Stages * STG) + wave * 64, g.prof ? &n_batches : nullptr);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4 * kK2RowTiles; ++u) {
           cq_r[u] = stv.cq[u];
           cnt_r[u] = stv.cnt[u];
         }

@@ -220,9 +220,9 @@ def test_knn2_scan_loop_keeps_clear_of_scratch_and_of_uncounted_waits():
     barriers = [i for i, l in enumerate(lines) if "s_barrier" in l and i < mfma[0]]
     assert barriers, "no barrier in front of the scan loop's MFMAs"
     # ... and on through the append path to the DMA issue of chunk c + 3 that ends the iteration
-    dma = [i for i, l in enumerate(lines) if "global_load_lds" in l and mfma[-1] < i < mfma[-1] + 700]
+    dma = [i for i, l in enumerate(lines) if "global_load_lds" in l and mfma[-1] < i < mfma[-1] + 3000]
     assert dma, "no DMA issue behind the scan loop's MFMAs"
     loop = lines[barriers[-1]: dma[-1] + 1]
-    assert len(loop) < 1200, "unexpected loop shape (%d instructions in the scan iteration)" % len(loop)
+    assert len(loop) < 4000, "unexpected loop shape (%d instructions in the scan iteration)" % len(loop)
     bad = [l.strip() for l in loop if "scratch_" in l or re.search(r"s_waitcnt\s+vmcnt\(0\)\s*$", l)]
     assert not bad, bad[:4]
