@@ -81,7 +81,13 @@ __global__ __launch_bounds__(256) void knn2_colsum_kernel(const double* __restri
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
   double s = 0.0;
   if (d < k)
-    for (int64_t r = r0 + sub; r < r1; r += 4) s += x[r * k + d];
+    for (int64_t r = r0 + sub; r < r1; r += 4) {
+      // non-finite coordinates stay out of the mean: ONE NaN in the cloud would otherwise make every centred coordinate NaN,
+      // every pair would pass the filter, and the scan would degenerate into the exact re-check of all N x N_q pairs
+      // (the centre only has to be near the cloud; a non-finite point itself still goes through the re-check and sorts last)
+      const double v = x[r * k + d];
+      if (fabs(v) < 1.0e300) s += v;
+    }
   red[threadIdx.x] = s;
   __syncthreads();
   if (sub == 0 && d < k) partial[(int64_t)blockIdx.x * 64 + d] = (red[d] + red[64 + d]) + (red[128 + d] + red[192 + d]);

@@ -319,3 +319,33 @@ def test_many_neighbours_on_a_large_cloud_take_the_scan_whose_lists_fit(ctx):
     assert nreg == 0
     go = aso.create_grad_mat(aso.PolyGradientEstimator(x, y, 1, n_nbrs), xq[:6])
     assert np.max(np.abs(g[:, :6] - go)) <= 1e-9 * np.abs(go).max()
+
+
+def test_non_finite_support_points_never_become_neighbours_and_do_not_slow_the_scan(ctx, monkeypatch):
+    """A few NaN / inf rows in the cloud: their distances are non-finite and sort last (like numpy's argsort of a NaN), so
+    the gradients are those of the cloud without them; and they must not enter the centre the filter works around -- one
+    NaN there would make every pair pass the filter, i.e. turn the scan into the exact re-check of all pairs."""
+    import time
+    rng = np.random.default_rng(31)
+    n, k, n_nbrs, nq = 60_000, 16, 40, 512
+    x = rng.standard_normal((n, k))
+    y = np.sin(x @ rng.standard_normal(k) * 0.3)
+    bad = rng.permutation(n)[:7]
+    xb = x.copy()
+    xb[bad[:3], 2] = np.nan
+    xb[bad[3:5], 0] = np.inf
+    xb[bad[5:], 5] = -np.inf
+    keep = np.setdiff1d(np.arange(n), bad)
+    xq = x[keep[rng.permutation(keep.size)[:nq]]]
+    monkeypatch.setenv("CORRLA_KNN", "3")
+    ctx.grad_mat(x, y, 1, n_nbrs, xq[:8])                     # warm-up (code object, workspaces)
+    t0 = time.perf_counter()
+    g_bad, nreg = ctx.grad_mat(xb, y, 1, n_nbrs, xq)
+    t_bad = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g_ref, nreg_ref = ctx.grad_mat(x[keep], y[keep], 1, n_nbrs, xq)
+    t_ref = time.perf_counter() - t0
+    monkeypatch.delenv("CORRLA_KNN")
+    assert nreg == nreg_ref == 0
+    assert np.max(np.abs(g_bad - g_ref)) <= 1e-9 * np.abs(g_ref).max()
+    assert t_bad < 5.0 * t_ref + 0.5, (t_bad, t_ref)
