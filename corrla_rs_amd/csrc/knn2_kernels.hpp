@@ -38,7 +38,8 @@ namespace corrla {
 namespace k {
 
 constexpr int kK2Waves = 12;            // scanning waves per workgroup = 3 per SIMD (168 VGPRs: at 4 per SIMD the query fragments spill;
-                                        // 8 waves x 4 row tiles at 256 VGPRs measured 446 vs 436 ms at 1e6 points)
+                                        // 8 waves x 4 row tiles at 256 VGPRs measured 446 vs 436 ms at 1e6 points; two chunks
+                                        // per ring slot and barrier 455 ms: the longer live ranges put scratch into the loop)
 constexpr int kK2RowTiles = 2;          // 16-query MFMA row tiles per wave: every B fragment read from LDS serves both
                                         // (with one, the 16 waves' fragment reads -- 256 KiB per chunk and CU at 128 B/clk
                                         // -- outweighed the MFMAs)

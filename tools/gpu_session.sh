@@ -8,7 +8,7 @@
 # GPU step times out nothing else is started in the same call.  A failing step (any other non-zero exit) is reported
 # and the session goes on.  Before the first step the library is checked (tests/test_abi.py: loads, exports every symbol, the
 # device code object holds every kernel the host code launches): a broken build ends the session in seconds instead of
-# aborting every step.  tools/plans/standard.plan = the round-end sequence (GPU tests, smoke, default bench);
+# aborting every step (SKIP_PREFLIGHT=1 in the environment skips it, e.g. to time a build that fails the ISA guard).  tools/plans/standard.plan = the round-end sequence (GPU tests, smoke, default bench);
 # plans of one-off experiments are not tracked (tools/plans/.gitignore).
 set -u
 PLAN=${1:?usage: gpu_session.sh PLAN [OUTDIR]}
@@ -18,7 +18,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 : > "$OUT/session.log"
-if ! timeout -k 10 300 python3 -m pytest tests/test_abi.py -x -q > "$OUT/preflight.log" 2>&1; then
+if [[ -z "${SKIP_PREFLIGHT:-}" ]] && ! timeout -k 10 300 python3 -m pytest tests/test_abi.py -x -q > "$OUT/preflight.log" 2>&1; then
   echo "!! preflight failed: the library in this snapshot is broken, nothing was run" | tee -a "$OUT/session.log"
   tail -n 25 "$OUT/preflight.log"
   exit 1
