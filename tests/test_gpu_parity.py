@@ -549,8 +549,12 @@ def test_householder_tsqr_rsvd_on_the_golden_fixtures(ctx, name, dtype):
     uo, so, vo = orc.random_svd(g["A"], g["k"], g["q"], g["p"], omega=g["omega"])
     tol = 1e-9 if dtype == np.float64 else 2e-4
     assert np.max(np.abs(s.ravel() - so.ravel())) < tol * so[0, 0]
-    if dtype == np.float64 or name in ("tall64x48", "gauss512x256", "fat48x64"):   # f32: the well-posed sketches
-        assert abs(orc.relerr(a, u, s, vt) - orc.relerr(g["A"], uo, so, vo)) < (1e-9 if dtype == np.float64 else 1e-5)
+    # f32 on the fixtures whose sketch f32 cannot resolve (decaying spectra after un-orthonormalised
+    # power iterations, exactly rank-deficient input) is held to the bound the default path's golden test uses for them
+    # (round 2 skipped the comparison there)
+    well_posed = dtype == np.float64 or name in ("tall64x48", "gauss512x256", "fat48x64")
+    rtol = (1e-9 if dtype == np.float64 else 1e-5) if well_posed else 2e-2
+    assert abs(orc.relerr(a, u, s, vt) - orc.relerr(g["A"], uo, so, vo)) < rtol
     k = g["k"]
     otol = 1e-12 if dtype == np.float64 else 2e-5
     assert np.max(np.abs(u.T.astype(np.float64) @ u - np.eye(k))) < otol
