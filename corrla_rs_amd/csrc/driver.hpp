@@ -184,7 +184,8 @@ struct RsvdDriver {
       dev.weighted_colsum(y, a.mt, a.mu_tall, v);
       dev.rank1_sub(z, a.nt, a.mu_short, v, scale_dev);
     }
-    if (sharded) dev.allreduce(z.p, (size_t)z.ld * (size_t)z.cols_alloc);
+    // (only the l columns that exist: the padding columns up to cols_alloc are zero on every rank and stay zero)
+    if (sharded) dev.allreduce(z.p, (size_t)z.ld * (size_t)z.cols);
   }
 
   // ---- thin-Q orthonormalisation (replaces y.qr().compute_thin_q(), random_svd.rs:38,57) ----
@@ -738,7 +739,7 @@ struct RsvdDriver {
         if (i == 0) dev.event_mark(0);
         dev.ata_fused(a.mem, i == 0 ? om : z, z);
         if (i == 0) dev.event_mark(1);
-        if (o.sharded) dev.allreduce(z.p, (size_t)z.ld * (size_t)z.cols_alloc);
+        if (o.sharded) dev.allreduce(z.p, (size_t)z.ld * (size_t)z.cols);
         dev.inv_norm(z, ss_dev, inv_dev);
         dev.scale_inplace(z, inv_dev);
         if (i == 0) phase(tm.sketch_ms, pt);
