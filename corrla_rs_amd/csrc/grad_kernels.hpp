@@ -756,66 +756,98 @@ __global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __res
       for (int off = 32; off > 0; off >>= 1) dm = fmax(dm, __shfl_xor(dm, off, 64));
       dmax = dm;
     }
-    // ---- Cholesky of the augmented system, left-looking, FIXED row ownership: lane r keeps rows r and 64 + r of the
-    // P + 1 <= 66 rows.  Per pivot j a lane computes ONE dot product (its row against row j: broadcast reads) and updates
-    // its running diagonal  G_rr - sum_p L_rp^2  in a register, from which pivot r is read when its turn comes (readlane:
-    // no LDS round trip, and the 64 copies of the diagonal's dot product that the floating ownership computed are gone);
-    // row P is the right-hand side, so its factor row is the forward-solved z = L^-1 b and only the back substitution is
-    // left.  One barrier per pivot.  (CORRLA_KNN2_PROF on the first version: Cholesky 64 % of the kernel, 12 % of its LDS
-    // cycles bank conflicts.)
+    // ---- Cholesky of the augmented system, BLOCKED left-looking, fixed row ownership: lane r keeps rows r and 64 + r of
+    // the P + 1 <= 66 rows (row P is the right-hand side: its factor row is the forward-solved z = L^-1 b, only the back
+    // substitution is left afterwards).
+    //  * Panels of 16 pivot columns.  Before a panel, the contribution of ALL earlier panels is taken off its columns by
+    //    v_mfma_f64_16x16x4_f64, one 16 x 16 tile of rows at a time:  C(I, J) -= sum_p L(I, p) L(J, p)^T  -- both operands
+    //    are read the same way (lane (c, g) of step s: L[16 T + c][16 p + 4 s + g]) straight from the row-packed image.
+    //  * Inside a panel, per pivot j a lane computes ONE dot product of at most 15 terms (its row against row j over the
+    //    panel's columns: broadcast reads, two doubles per LDS instruction) and keeps the running diagonal of its row in
+    //    a register, from which pivot r is read by v_readlane when its turn comes.  One barrier per pivot.
+    // (Tick counters, CORRLA_KNN2_PROF: the unblocked form -- dot products over all earlier columns, 32 half-rate v_fma_f64
+    //  per lane and pivot on average -- was 59 % of the kernel.)
     if (prof && attempt == 0) tp1 = wall_clock64();
     const int nrows = P + 1;
     const int r0 = lane, r1 = 64 + lane;
     double* const row0 = M + myoff0;
     double* const row1 = M + myoff1;
-    double dg0 = r0 < P ? row0[r0] : 0.0, dg1 = r1 < P ? row1[r1] : 0.0;
+    double dg0 = 0.0, dg1 = 0.0;
     auto bcast = [&](double v, int src) __attribute__((always_inline)) -> double {  // src uniform
       const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
       return __hiloint2double(hi, lo);
     };
     typedef double f64x2v __attribute__((ext_vector_type(2)));
     bool ok = true;
-    for (int j = 0; j < P; ++j) {
-      const double sjj = j < 64 ? bcast(dg0, j) : bcast(dg1, j - 64);
-      if (!(sjj > 1e-13 * dmax)) {
-        ok = false;
-        break;  // uniform
-      }
-      double rinv = __builtin_amdgcn_rsq(sjj);
-      rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
-      rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
-      double* const rj = row_u(j);
-      auto dot = [&](const double* ri) __attribute__((always_inline)) -> double {
-        f64x2v t0 = {0.0, 0.0}, t1 = {0.0, 0.0}, t2 = {0.0, 0.0}, t3 = {0.0, 0.0};
-        int p2 = 0;
-        for (; p2 + 7 < j; p2 += 8) {
-          t0 += *(const f64x2v*)(ri + p2) * *(const f64x2v*)(rj + p2);
-          t1 += *(const f64x2v*)(ri + p2 + 2) * *(const f64x2v*)(rj + p2 + 2);
-          t2 += *(const f64x2v*)(ri + p2 + 4) * *(const f64x2v*)(rj + p2 + 4);
-          t3 += *(const f64x2v*)(ri + p2 + 6) * *(const f64x2v*)(rj + p2 + 6);
+    for (int J = 0; J < NTT && ok; ++J) {
+      const int c0 = 16 * J, c1 = min(c0 + 16, P);
+      if (c0 >= P) break;  // (a last tile that only holds the right-hand side row has no pivots)
+      if (J > 0) {
+        // C(I, J) -= sum_{p < J} L(I, p) L(J, p)^T for the row tiles I >= J
+        const int bj = c0 + fr;                                    // pivot row this lane feeds as the B operand
+        const double* bptr = row(bj < P ? bj : 0);
+        for (int I = J; I < NTT; ++I) {
+          const int ai = 16 * I + fr;
+          const double* aptr = row(ai <= P ? ai : 0);
+          f64x4v acc4 = {0.0, 0.0, 0.0, 0.0};
+          for (int pk = 0; pk < 4 * J; ++pk) {                     // k-steps of 4 columns over the earlier panels
+            const int col = 4 * pk + fg;
+            const double av = ai <= P ? -aptr[col] : 0.0;
+            const double bv = bj < P ? bptr[col] : 0.0;
+            acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc4, 0, 0, 0);
+          }
+          // D: column = lane & 15, row = (lane >> 4) + 4 reg
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int i = 16 * I + fg + 4 * rg, jj = c0 + fr;
+            if (jj < P && ((i < P && jj <= i) || i == P)) row(i)[jj] += acc4[rg];
+          }
         }
-        for (; p2 + 1 < j; p2 += 2) t0 += *(const f64x2v*)(ri + p2) * *(const f64x2v*)(rj + p2);
-        double tail = 0.0;
-        if (p2 < j) tail = ri[p2] * rj[p2];
-        const f64x2v tt = (t0 + t1) + (t2 + t3);
-        return (tt[0] + tt[1]) + tail;
-      };
-      const bool a0 = r0 > j && r0 < nrows, a1 = r1 > j && r1 < nrows;
-      if (a0) {
-        const double c = (row0[j] - dot(row0)) * rinv;
-        row0[j] = c;
-        dg0 -= c * c;
+        __syncthreads();
       }
-      if (a1) {
-        const double c = (row1[j] - dot(row1)) * rinv;
-        row1[j] = c;
-        dg1 -= c * c;
+      // running diagonals of the panel's rows start from the updated image
+      if (r0 >= c0 && r0 < c1) dg0 = row0[r0];
+      if (r1 >= c0 && r1 < c1) dg1 = row1[r1];
+      for (int j = c0; j < c1; ++j) {
+        const double sjj = j < 64 ? bcast(dg0, j) : bcast(dg1, j - 64);
+        if (!(sjj > 1e-13 * dmax)) {
+          ok = false;
+          break;  // uniform
+        }
+        double rinv = __builtin_amdgcn_rsq(sjj);
+        rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
+        rinv = rinv * (1.5 - 0.5 * sjj * rinv * rinv);
+        double* const rj = row_u(j);
+        auto dot = [&](const double* ri) __attribute__((always_inline)) -> double {  // over the panel's columns c0 .. j - 1
+          f64x2v t0 = {0.0, 0.0}, t1 = {0.0, 0.0};
+          int p2 = c0;
+          for (; p2 + 3 < j; p2 += 4) {
+            t0 += *(const f64x2v*)(ri + p2) * *(const f64x2v*)(rj + p2);
+            t1 += *(const f64x2v*)(ri + p2 + 2) * *(const f64x2v*)(rj + p2 + 2);
+          }
+          for (; p2 + 1 < j; p2 += 2) t0 += *(const f64x2v*)(ri + p2) * *(const f64x2v*)(rj + p2);
+          double tail = 0.0;
+          if (p2 < j) tail = ri[p2] * rj[p2];
+          const f64x2v tt = t0 + t1;
+          return (tt[0] + tt[1]) + tail;
+        };
+        const bool a0 = r0 > j && r0 < nrows, a1 = r1 > j && r1 < nrows;
+        if (a0) {
+          const double c = (row0[j] - dot(row0)) * rinv;
+          row0[j] = c;
+          dg0 -= c * c;
+        }
+        if (a1) {
+          const double c = (row1[j] - dot(row1)) * rinv;
+          row1[j] = c;
+          dg1 -= c * c;
+        }
+        if (lane == (j & 63)) {  // the owner of row j
+          rj[j] = sjj * rinv;
+          dinv[j] = rinv;
+        }
+        __syncthreads();  // column j of the factor is in LDS before pivot j + 1 reads row j + 1 up to it
       }
-      if (lane == (j & 63)) {  // the owner of row j
-        rj[j] = sjj * rinv;
-        dinv[j] = rinv;
-      }
-      __syncthreads();  // column j of the factor is in LDS before pivot j + 1 reads row j + 1 up to it
     }
     if (ok) break;
     if (attempt == 1) {
