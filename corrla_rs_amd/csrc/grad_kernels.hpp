@@ -663,7 +663,7 @@ __global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __res
   // row starts: a lane keeps those of its own rows (lane, 64 + lane) in registers -- a pivot row's start is a readlane
   // away (a per-pivot load from the argument block cost more than the bank conflicts the table removes) -- and a copy in
   // LDS serves the per-lane lookups of the store after the Gram products
-  unsigned short* offl = (unsigned short*)(nidx + ((n_nbrs + 3) & ~3));  // [128]
+  unsigned short* offl = (unsigned short*)(nidx + (((n_nbrs + 15) & ~15) + 16));  // [128]
   const int myoff0 = tab.off[threadIdx.x & 63], myoff1 = (threadIdx.x & 63) + 64 <= P ? tab.off[(threadIdx.x & 63) + 64] : 0;
   offl[threadIdx.x & 63] = (unsigned short)myoff0;
   offl[64 + (threadIdx.x & 63)] = (unsigned short)myoff1;
@@ -674,8 +674,10 @@ __global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __res
   const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
   const int64_t q = blockIdx.x;
   if (q >= n_q) return;
-  const int n4 = (n_nbrs + 3) & ~3;
-  for (int r = lane; r < n4; r += 64) nidx[r] = r < n_nbrs ? nbr[q * n_nbrs + r] : -1;
+  // neighbour groups of 4 (one MFMA k-step), padded with -1 (a zero row of the design) to whole rounds of four groups
+  // plus one round the pipeline below reads ahead
+  const int n16 = (n_nbrs + 15) & ~15;
+  for (int r = lane; r < n16 + 16; r += 64) nidx[r] = r < n_nbrs ? nbr[q * n_nbrs + r] : -1;
   // this lane's columns of the design: x0 for the coordinate columns
   double x0c[NTT];
 #pragma unroll
@@ -693,49 +695,56 @@ __global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __res
     for (int a = 0; a < NTT; ++a)
 #pragma unroll
       for (int b = 0; b < NTT; ++b) acc[a][b] = (f64x4v){0, 0, 0, 0};
-    const int nsteps = n4 >> 2;
-    // branch-free (every lane loads: a clamped row, a clamped column, y of that row) so that several neighbour groups can
-    // be in flight at once -- the gather is a chain of dependent DRAM round trips otherwise (20 of them at 80 neighbours)
-    auto fragment = [&](int s, double (&fv)[NTT]) __attribute__((always_inline)) {
-      const int idx = nidx[4 * s + fg];
-      const int64_t id = idx >= 0 ? idx : 0;
-      const double yv = y[id];
+    const int nsteps = n16 >> 2;  // a multiple of 4
+    // The gather: branch-free (every lane loads a clamped row at a clamped column, and y of that row) and RAW -- a group's
+    // NTT + 1 loads are issued back to back and nothing touches the values until its products are due, four groups later.
+    // (Round 3's first version subtracted x0 right behind each load: hipcc then waited for every single load, 100
+    // dependent DRAM round trips per query at 80 neighbours, and the conditional tail of the pipeline kept the waits at
+    // vmcnt(0).  Padding the neighbour list to whole rounds makes the pipeline branch-free.)
+    struct Group {
+      double xr[NTT], yr;
+      int idx;
+    };
+    auto fragment = [&](int s, Group& gsrc) __attribute__((always_inline)) {
+      gsrc.idx = nidx[4 * s + fg];
+      const int64_t id = gsrc.idx >= 0 ? gsrc.idx : 0;
 #pragma unroll
       for (int t = 0; t < NTT; ++t) {
         const int col = 16 * t + fr;
-        const double xv = x[id * k + (col < k ? col : k - 1)];
-        double v = xv - x0c[t];
-        v = col < k ? v : (col == k ? 1.0 : (col == k + 1 ? yv : 0.0));
-        fv[t] = idx >= 0 ? v : 0.0;
+        gsrc.xr[t] = x[id * k + (col < k ? col : k - 1)];
       }
+      gsrc.yr = y[id];
     };
-    auto products = [&](const double (&fv)[NTT]) __attribute__((always_inline)) {
+    auto products = [&](const Group& gsrc) __attribute__((always_inline)) {
+      double fv[NTT];
+#pragma unroll
+      for (int t = 0; t < NTT; ++t) {
+        const int col = 16 * t + fr;
+        double v = gsrc.xr[t] - x0c[t];
+        v = col < k ? v : (col == k ? 1.0 : (col == k + 1 ? gsrc.yr : 0.0));
+        fv[t] = gsrc.idx >= 0 ? v : 0.0;
+      }
 #pragma unroll
       for (int a = 0; a < NTT; ++a)
 #pragma unroll
         for (int b = 0; b <= a; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[a], fv[b], acc[a][b], 0, 0, 0);
     };
-    // four neighbour groups in flight: the loads of step s + 4 are issued right after the MFMAs of step s
-    double f0[NTT], f1[NTT], f2[NTT], f3[NTT];
+    // four neighbour groups in flight: the loads of step s + 4 are issued right after the MFMAs of step s (the last round
+    // reads one round of padding ahead: rows of point 0, never used)
+    Group f0, f1, f2, f3;
     fragment(0, f0);
-    if (1 < nsteps) fragment(1, f1);
-    if (2 < nsteps) fragment(2, f2);
-    if (3 < nsteps) fragment(3, f3);
+    fragment(1, f1);
+    fragment(2, f2);
+    fragment(3, f3);
     for (int s = 0; s < nsteps; s += 4) {
       products(f0);
-      if (s + 4 < nsteps) fragment(s + 4, f0);
-      if (s + 1 < nsteps) {
-        products(f1);
-        if (s + 5 < nsteps) fragment(s + 5, f1);
-      }
-      if (s + 2 < nsteps) {
-        products(f2);
-        if (s + 6 < nsteps) fragment(s + 6, f2);
-      }
-      if (s + 3 < nsteps) {
-        products(f3);
-        if (s + 7 < nsteps) fragment(s + 7, f3);
-      }
+      fragment(s + 4, f0);
+      products(f1);
+      fragment(s + 5, f1);
+      products(f2);
+      fragment(s + 6, f2);
+      products(f3);
+      fragment(s + 7, f3);
     }
     // D layout of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 reg
 #pragma unroll
@@ -883,7 +892,7 @@ __global__ __launch_bounds__(64, 2) void grad_fit_lin_kernel(const double* __res
 }
 inline size_t grad_fit_lin_lds_bytes(int k, int n_nbrs) {
   const int P = k + 1;
-  return ((size_t)grad_fit_lin_row_table(P).total + 2 * P) * 8 + (size_t)((n_nbrs + 3) & ~3) * 4 + 128 * 2 + 64;
+  return ((size_t)grad_fit_lin_row_table(P).total + 2 * P) * 8 + (size_t)(((n_nbrs + 15) & ~15) + 16) * 4 + 128 * 2 + 64;
 }
 
 // m_in_lds = false: the normal equations live in global memory (grad_fit_kernel's m_glob)
