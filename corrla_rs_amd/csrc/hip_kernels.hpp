@@ -2372,14 +2372,23 @@ __global__ __launch_bounds__(chol_inv_max_threads<T>()) void chol_inv_kernel(con
   T v[4][4], w[4][4];
   float dv = 0.f, gm = 0.f;
   int bad = 0;
+  // the tile's 16 loads are unconditional (clamped indices) and issued together: one branch per element put an
+  // s_waitcnt vmcnt(0) behind every load -- 16 dependent L2 round trips in front of the elimination
+#pragma unroll
+  for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = min(i0 + aa, r - 1), k = min(k0 + b, r - 1);
+      v[aa][b] = g[(int64_t)k * ldg + i];
+    }
 #pragma unroll
   for (int aa = 0; aa < 4; ++aa)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int i = i0 + aa, k = k0 + b;
-      T x = (T)0;
-      if (own && i < r && k < r) {
-        x = g[(int64_t)k * ldg + i];
+      const bool in = own && i < r && k < r;
+      const T x = in ? v[aa][b] : (T)0;
+      if (in) {
         if (!((float)fabs(x) < 3.0e38f)) bad = 1;
         dv = fmaxf(dv, (float)fabs(x - (i == k ? (T)1 : (T)0)));
         if (i == k) gm = fmaxf(gm, (float)x);
@@ -2714,15 +2723,18 @@ __global__ __launch_bounds__(256) void column_sign_apply_kernel(T* v, int64_t ld
   T* col = v + (int64_t)j * ld;
   T best = (T)-1;
   int64_t best_i = 0;
-  for (int64_t i0 = threadIdx.x; i0 < rows; i0 += 4 * (int64_t)blockDim.x) {  // four loads in flight
-    T a[4];
+  for (int64_t i0 = threadIdx.x; i0 < rows; i0 += 8 * (int64_t)blockDim.x) {  // eight loads in flight
+    // (clamped, unconditional loads: behind a branch each one gets an s_waitcnt vmcnt(0) of its own)
+    T a[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int64_t i = i0 + u * (int64_t)blockDim.x;
-      a[u] = i < rows ? fabs(col[i]) : (T)-1;
+      a[u] = col[i < rows ? i : rows - 1];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u) a[u] = i0 + u * (int64_t)blockDim.x < rows ? (T)fabs(a[u]) : (T)-1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
       if (a[u] > best) {  // increasing i: the first maximum wins
         best = a[u];
         best_i = i0 + u * (int64_t)blockDim.x;

@@ -108,11 +108,23 @@ __global__ __launch_bounds__(1024) void jmc_init_kernel(const T* __restrict__ c,
   if (tid == 0) sbad = 0;
   float mx = 0.f;
   int bad = 0;
-  for (int idx = tid; idx < l * l; idx += 1024) {
-    const int j = idx / l, i = idx - j * l;
-    const float x = (float)fabs(c[(int64_t)j * ldc + i]);
-    if (!(x < 3.0e38f)) bad = 1;
-    mx = fmaxf(mx, x);
+  // (loads in batches of four, clamped and unconditional: one load per loop iteration is one dependent L2 round trip per
+  //  iteration -- this one-workgroup kernel was 20 us of round trips at l = 138)
+  for (int idx0 = tid; idx0 < l * l; idx0 += 4 * 1024) {
+    T xb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(idx0 + u * 1024, l * l - 1);
+      const int j = idx / l, i = idx - j * l;
+      xb[u] = c[(int64_t)j * ldc + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (idx0 + u * 1024 < l * l) {
+        const float x = (float)fabs(xb[u]);
+        if (!(x < 3.0e38f)) bad = 1;
+        mx = fmaxf(mx, x);
+      }
   }
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   if ((tid & 63) == 0) red[tid >> 6] = mx;
@@ -127,11 +139,24 @@ __global__ __launch_bounds__(1024) void jmc_init_kernel(const T* __restrict__ c,
     sexp = 1 - sexp;  // mx * 2^sexp in [1, 2)
   }
   const int total = rp * ncols_pad;
-  for (int idx = tid; idx < total; idx += 1024) {
-    const int j = idx / rp, i = idx - j * rp;
-    const bool in = i < l && j < l;
-    w[idx] = in ? (T)ldexp((double)c[(int64_t)j * ldc + i], sexp) : (T)0;
-    v[idx] = (in && i == j) ? (T)1 : (T)0;
+  for (int idx0 = tid; idx0 < total; idx0 += 4 * 1024) {
+    T xb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(idx0 + u * 1024, total - 1);
+      const int j = idx / rp, i = idx - j * rp;
+      xb[u] = c[(int64_t)min(j, l - 1) * ldc + min(i, l - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + u * 1024;
+      if (idx < total) {
+        const int j = idx / rp, i = idx - j * rp;
+        const bool in = i < l && j < l;
+        w[idx] = in ? (T)ldexp((double)xb[u], sexp) : (T)0;
+        v[idx] = (in && i == j) ? (T)1 : (T)0;
+      }
+    }
   }
   for (int i = tid; i <= kJmcMaxSweeps; i += 1024) {
     ctl->rot[i] = 0;
@@ -445,9 +470,14 @@ __global__ __launch_bounds__(1024) void jmc_finish_kernel(const T* w, const T* v
   const int tid = threadIdx.x, group = tid >> 4, gl = tid & 15;
   for (int j = group; j < l; j += 64) {
     T a = 0;
-    for (int i = gl; i < l; i += 16) {
-      const T xx = w[(int64_t)j * rp + i];
-      a += xx * xx;
+    // (six loads in flight, accumulated in the order of the plain loop)
+    for (int i0 = gl; i0 < l; i0 += 6 * 16) {
+      T xb[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) xb[u] = w[(int64_t)j * rp + min(i0 + 16 * u, l - 1)];
+#pragma unroll
+      for (int u = 0; u < 6; ++u)
+        if (i0 + 16 * u < l) a += xb[u] * xb[u];
     }
 #pragma unroll
     for (int msk = 1; msk < 16; msk <<= 1) a += __shfl_xor(a, msk, 16);
@@ -472,9 +502,22 @@ __global__ __launch_bounds__(1024) void jmc_finish_kernel(const T* w, const T* v
     const int j = order[r];
     const T sj = sigma[j];
     const T inv = sj > (T)0 ? (T)1 / sj : (T)0;
-    for (int i = gl; i < l; i += 16) {
-      m2[(int64_t)r * ld2 + i] = w[(int64_t)j * rp + i] * inv;
-      if (with_v) m1[(int64_t)r * ld1 + i] = v[(int64_t)j * rp + i];
+    for (int i0 = gl; i0 < l; i0 += 6 * 16) {
+      T wb[6], vb[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int i = min(i0 + 16 * u, l - 1);
+        wb[u] = w[(int64_t)j * rp + i];
+        vb[u] = with_v ? v[(int64_t)j * rp + i] : (T)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int i = i0 + 16 * u;
+        if (i < l) {
+          m2[(int64_t)r * ld2 + i] = wb[u] * inv;
+          if (with_v) m1[(int64_t)r * ld1 + i] = vb[u];
+        }
+      }
     }
     if (gl == 0) s_out[r] = (T)ldexp((double)sj, -sexp);
   }

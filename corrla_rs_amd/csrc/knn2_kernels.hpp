@@ -256,6 +256,8 @@ __device__ __forceinline__ void k2_flush_wave(const double* __restrict__ x, cons
     l0.i = __hip_atomic_load(li_w + qi * kK2List + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     l1.d = __hip_atomic_load(ld_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     l1.i = __hip_atomic_load(li_w + qi * kK2List + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the first 64 candidate indices travel with the list: one memory round trip fewer per query)
+    const int cand0 = lane < ncand ? __hip_atomic_load(cand_w + qi * kK2Cap + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
     // the query's row goes to LDS once (wave-private): the re-check reads it as broadcasts instead of holding it in
     // registers next to the candidate's row.  (Loading list, row and the first candidate indices one query ahead was
     // tried: the flush got no faster and the scan loop's register allocation suffered -- 435 -> 532 ms.)
@@ -269,7 +271,7 @@ __device__ __forceinline__ void k2_flush_wave(const double* __restrict__ x, cons
       c.d = inf;
       c.i = 0x7fffffff;
       if (b0 + lane < ncand) {
-        c.i = __hip_atomic_load(cand_w + qi * kK2Cap + b0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.i = b0 == 0 ? cand0 : __hip_atomic_load(cand_w + qi * kK2Cap + b0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double* pp = x + (int64_t)c.i * kdim;
         double s0 = 0.0, s1 = 0.0;
         int d = 0;
