@@ -228,7 +228,12 @@ __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename 
     dst = g.slab + (int64_t)blockIdx.z * g.slab_stride;
   } else {
     dst = g.out;
-    if (g.scale) sc = *g.scale;
+    if (g.scale) {
+      sc = *g.scale;
+      // retire the load HERE: the stores below sit in branches of their own, and hipcc, not knowing across blocks whether
+      // `sc` has landed, put an s_waitcnt vmcnt(0) in front of every one of them -- which also waits for the store before
+      asm volatile("" : "+v"(sc));
+    }
   }
   if constexpr (MT<T>::kBigIsA) {
     // D: column = lane & 15 (result column), rows 4 (lane >> 4) + j (outer indices)
@@ -252,12 +257,22 @@ __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename 
   } else {
     const int64_t outer = outer0 + (lane & 15);
     if (outer >= outer_limit) return;
+    // f64: D register j of column tile t is result column col0 + 16 t + 4 j + (lane >> 4), i.e. the 4 NT stores of a lane are
+    // 4 out_ld elements apart: ONE running pointer.  (With `dst[col * out_ld + outer]` hipcc computed the 36 addresses
+    // ahead of the reduction loop and parked them in scratch; every store then sat behind a scratch reload and an
+    // s_waitcnt vmcnt(0) that also waited for the STORE before it -- ~50 us per outer tile, a third of the short-reduction
+    // products of the f64 thin-Q.)
+    static_assert(sizeof(T) == 8, "the scalar-store epilogue is the f64 layout (drow = (lane >> 4) + 4 j)");
+    const int64_t colb = col0 + (lane >> 4);
+    T* p = dst + colb * g.out_ld + outer;
+    const int64_t step = 4 * g.out_ld;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t col = col0 + 16 * t + MT<T>::drow(lane, j);
-        if (g.nsplit > 1 || col < g.out_cols) dst[col * g.out_ld + outer] = acc[t][j] * sc;
+        const int64_t col = colb + 16 * t + 4 * j;
+        if (g.nsplit > 1 || col < g.out_cols) *p = acc[t][j] * sc;
+        p += step;
       }
     }
   }
