@@ -205,9 +205,15 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
                                                         T tol, T tol_early, T floor2, JmcCtl* ctl) {
   typedef typename JmcVec<T>::v2 v2;
   constexpr int PITCH = jmc_pitch(NC, (int)sizeof(T), LANES);
+  // The control words this launch depends on are loaded TOGETHER, unconditionally (clamped index): tested one after the
+  // other, each sat in a branch of its own behind an s_waitcnt vmcnt(0) -- three to four dependent L2 round trips at the
+  // head of every one of the ~45 launches of a call.
+  const int sp = sweep > 0 ? sweep - 1 : 0;
+  const unsigned rot_prev = ctl->rot[sp], big_prev = ctl->big[sp];
+  const int bad_in = ctl->bad, with_v_in = ctl->with_v;
   // converged in an earlier sweep (the flags were written by earlier launches): nothing to do
-  if (sweep > 0 && !(ctl->rot[sweep - 1] && ctl->big[sweep - 1])) return;
-  if (ctl->bad) return;  // non-finite input: the finish kernel reports it
+  if (sweep > 0 && !(rot_prev && big_prev)) return;
+  if (bad_in) return;  // non-finite input: the finish kernel reports it
   if (threadIdx.x == 0 && blockIdx.x == 0 && ctl->t_last != 0) {  // diagnostic: span of the PREVIOUS launch
     ctl->t_span += ctl->t_last - ctl->t_first;
     ctl->t_first = ~0ull;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
   int bp, bq;
   tournament_pair(nblocks, step, blockIdx.x, bp, bq);
   if (tid < 2) flag[tid] = 0;
-  const bool with_v = ctl->with_v != 0;  // uniform over the grid
+  const bool with_v = with_v_in != 0;  // uniform over the grid
   const long long ts0 = wall_clock64();
   // ---- load the 2b columns of W and V: four contiguous segments (W_P, W_Q, V_P, V_Q), by LDS-DMA ----
   // (a register-staged copy loop serialises one L2 round trip per iteration: 18 of them at l = 266 f64 cost

@@ -152,7 +152,10 @@ __device__ __forceinline__ void mx_store(const MxArgs& g, const f32x4 (&acc)[NT]
     dst = g.slab + (int64_t)blockIdx.z * g.slab_stride;
   } else {
     dst = g.out;
-    if (g.scale) sc = *g.scale;
+    if (g.scale) {
+      sc = *g.scale;
+      asm volatile("" : "+v"(sc));  // retire the load here (hip_kernels.hpp: store_tile)
+    }
   }
   const int64_t outer = outer0 + 4 * (lane >> 4);
   if (outer >= outer_limit) return;
