@@ -970,9 +970,12 @@ class HipDev {
     if (l < 2 || l > 288) return false;
     const int lanes = jmc_lanes<T>(l);
     const int nc = (int)((l + 2 * lanes - 1) / (2 * lanes));
+    // block width: a multiple of four columns (= whole waves of four 16-lane processors, whole sub-blocks of the
+    // wave-local schedule); CORRLA_JMC_LOCAL=0 keeps the round-2 rule (even)
+    const int local = env_int("CORRLA_JMC_LOCAL", 1);
     auto width = [&](int np_) {
       int bb = (int)((l + 2 * np_ - 1) / (2 * np_));
-      return bb + (bb & 1);
+      return local ? (bb + 3) / 4 * 4 : bb + (bb & 1);
     };
     int np = env_int("CORRLA_JMC_NP", 0);
     if (np <= 0) {
@@ -992,7 +995,7 @@ class HipDev {
     const size_t lds = k::jmc_lds_bytes(NC, b, sizeof(T), lanes);
     const unsigned threads = (unsigned)((b * lanes + 63) / 64 * 64);
     hipLaunchKernelGGL((k::jmc_step_kernel<T, NC, 16>), dim3((unsigned)np), dim3(threads), lds, stream, w, v, b, nblocks, step,
-                       sweep, step == 0 ? 1 : 0, tol, tol_early, floor2, ctl);
+                       sweep, step == 0 ? 1 : 0, tol, tol_early, floor2, ctl, jmc_local_);
   }
   // conv_status: device CholStatus record that receives the convergence verdict of the fixed number of sweeps
   // enqueued without any synchronisation (the caller checks it later); nullptr: sweeps are enqueued in groups and the
@@ -1001,6 +1004,7 @@ class HipDev {
   void small_svd_mc(const Skinny<T>& c, int64_t l, int64_t k, Skinny<T>& m1, Skinny<T>& m2, T* s_dev, void* conv_status) {
     int nc = 0, np = 0, b = 0;
     if (!jmc_geometry<T>(l, &nc, &np, &b)) throw Error(ST_EINVAL, "internal: core too large for the multi-workgroup Jacobi");
+    jmc_local_ = env_int("CORRLA_JMC_LOCAL", 1);  // 1: wave-local sub-block schedule (jacobi_mc_kernels.hpp), 0: ring schedule
     // global column pitch = LDS column pitch: a block of b columns is one contiguous byte range in both
     const int lanes = jmc_lanes<T>(l);
     const int rp = k::jmc_pitch(nc, (int)sizeof(T), lanes), nblocks = 2 * np, ncols_pad = nblocks * b;
@@ -1527,7 +1531,7 @@ class HipDev {
   int split_nn_override_ = 0, split_tn_override_ = 0, mw_override_ = 0, gemm_debug_flags_ = 0;
   uint64_t entropy_ = 0, calls_ = 0, calls_sharded_ = 0;
   bool no_device_chol_ = false;
-  int jmc_min_l_ = 96, jmc_max_b_ = 24;
+  int jmc_min_l_ = 96, jmc_max_b_ = 24, jmc_local_ = 1;
   int persist_max_tiles_ = 16;
   const int* run_if_ = nullptr;
   bool phase_events_ = true;

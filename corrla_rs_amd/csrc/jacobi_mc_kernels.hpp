@@ -198,11 +198,45 @@ __global__ __launch_bounds__(1024) void jmc_init_kernel(const T* __restrict__ c,
   }
 }
 
+// jacobi_rotation without its early exits: the same arithmetic in a straight line, (cs, sn, t) = (1, 0, 0) when the pair
+// is left alone (a column below floor2, |cos| <= tol, or the overflow guard) -- applying that "rotation" is exact.
+__device__ __forceinline__ bool jmc_rotation_flat(float a, float b, float g, float tol, float floor2, float& cs, float& sn,
+                                                  float& rel, float& t) {
+  const float rs = __builtin_amdgcn_rsqf(a) * __builtin_amdgcn_rsqf(b);
+  rel = fabsf(g) * rs;
+  const float zeta = (b - a) * 0.5f * __builtin_amdgcn_rcpf(g);
+  const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta);
+  const float t_ = copysignf(__builtin_amdgcn_rcpf(den), zeta);
+  const float c_ = __builtin_amdgcn_rsqf(1.f + t_ * t_);
+  const float s_ = c_ * t_;
+  const bool ok = (a > floor2) && (b > floor2) && (rel > tol) && (fabsf(s_) <= 1.f) && (c_ <= 1.f);
+  cs = ok ? c_ : 1.f;
+  sn = ok ? s_ : 0.f;
+  t = ok ? t_ : 0.f;
+  return ok;
+}
+__device__ __forceinline__ bool jmc_rotation_flat(double a, double b, double g, double tol, double floor2, double& cs,
+                                                  double& sn, double& rel, double& t) {
+  const double rs = jr_rsq(a) * jr_rsq(b);
+  rel = fabs(g) * rs;
+  const double zeta = (b - a) * 0.5 * jr_rcp(g);
+  const double w = 1.0 + zeta * zeta;
+  const double den = fabs(zeta) + w * jr_rsq(w);
+  const double t_ = copysign(jr_rcp(den), zeta);
+  const double c_ = jr_rsq(1.0 + t_ * t_);
+  const double s_ = c_ * t_;
+  const bool ok = (a > floor2) && (b > floor2) && (rel > tol) && (fabs(s_) <= 1.0) && (c_ <= 1.0);
+  cs = ok ? c_ : 1.0;
+  sn = ok ? s_ : 0.0;
+  t = ok ? t_ : 0.0;
+  return ok;
+}
+
 // One outer step.  grid = NP workgroups, block = b * LANES threads (rounded up to a wave; b <= 32, b even).
 // LANES = 16 is what runs; 8 (f32 only: half the waves per block pair, twice the column per lane) measured slower.
 template <class T, int NC, int LANES>
 __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nblocks, int step, int sweep, int within,
-                                                        T tol, T tol_early, T floor2, JmcCtl* ctl) {
+                                                        T tol, T tol_early, T floor2, JmcCtl* ctl, int local) {
   typedef typename JmcVec<T>::v2 v2;
   constexpr int PITCH = jmc_pitch(NC, (int)sizeof(T), LANES);
   // The control words this launch depends on are loaded TOGETHER, unconditionally (clamped index): tested one after the
@@ -324,6 +358,160 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
   };
   const long long clk0 = clock64(), wall0 = wall_clock64();
   const long long ts2 = wall0;
+  // ---- wave-local schedule (local != 0, LANES == 16: a wave = four processors) ----------------------------------
+  // The ring schedule below hands every Q column to the next processor once per round, across waves: one workgroup
+  // barrier per round, and the barrier (all waves drained + released) is about half of the ~0.55 us a round costs.
+  // Here the blocks are cut into SUB-BLOCKS of four columns, one per wave, and a wave meets a sub-block on its own:
+  //   inner4: processor i keeps A[i] in registers and rotates it against B[(i + r) mod 4], r = 0..3 -- all 16 pairs of
+  //           (A, B); the four B columns cross LDS, but they are touched by THIS wave only, and the LDS operations of
+  //           one wave complete in issue order: no barrier, only the data dependence.
+  //   cross : super-round s pairs wave k's sub-block of P with sub-block (k + s) mod NSB of Q; barrier per super-round
+  //           (NSB = b / 4 barriers instead of b).
+  //   within: a round-robin tournament over the sub-blocks of P (first half of the waves) and of Q (second half),
+  //           one inner4 per meeting, then the three rounds inside every sub-block (two processors per sub-block).
+  // Every pair of columns still meets exactly once per sweep; only the order differs.
+  auto inner4 = [&](auto wv, v2 (&x)[NC], v2 (&vx)[NC], T& na, int sb0) {
+    constexpr bool WV = decltype(wv)::value;  // V accumulated: the caller branches once, the rounds are straight lines
+    const int pi = proc & 3;
+    // b is a multiple of four here (the host's geometry): every processor has a column and every sub-block is full, so a
+    // round has no predicate at all.  The rotation is computed whether or not the pair needs one and applied as
+    // (cs, sn) = (1, 0) when it does not (jmc_rotation_flat); the loads of round r + 1 are issued right behind the stores
+    // of round r, ahead of the register half of the update (two register images of the B column, alternating).
+    constexpr bool DB = !(WV && sizeof(T) == 8 && NC > 4);  // f64 with V at l > 128: two images of B would spill
+    constexpr int NB = DB ? 2 : 1;
+    v2 y[NB][NC];
+    T nb[NB];
+    auto fetch = [&](int r, int buf) {
+      const int sy = sb0 + ((pi + r) & 3);
+      const T* cy = wl + (size_t)sy * PITCH + lane_off;
+      nb[buf] = nrm[sy];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) y[buf][c] = *(const v2*)(cy + c * 2 * LANES);
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cur = DB ? (r & 1) : 0;
+      const int sy = sb0 + ((pi + r) & 3);
+      T* cy = wl + (size_t)sy * PITCH + lane_off;
+      T* uy = vl + (size_t)sy * PITCH + lane_off;
+      v2 acc = x[0] * y[cur][0];
+#pragma unroll
+      for (int c = 1; c < NC; ++c) acc += x[c] * y[cur][c];
+      const T gg = jmc_sum<LANES>(acc[0] + acc[1]);
+      T cs, sn, t, rel;
+      const bool rot = jmc_rotation_flat(na, nb[cur], gg, tol, floor2, cs, sn, rel, t);
+      my_rot |= rot ? 1 : 0;
+      my_big |= (rot && rel > tol_early) ? 1 : 0;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) *(v2*)(cy + c * 2 * LANES) = sn * x[c] + cs * y[cur][c];
+      if (g == 0) nrm[sy] = nb[cur] + t * gg;
+      // the next inner round reads what other lanes of this wave have just written
+      asm volatile("" ::: "memory");
+      if (DB && r < 3) fetch(r + 1, cur ^ 1);
+      if (WV) {
+        // the V columns only receive the rotation: they are read here, behind the W traffic the next round waits for
+        v2 vy[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) vy[c] = *(const v2*)(uy + c * 2 * LANES);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          *(v2*)(uy + c * 2 * LANES) = sn * vx[c] + cs * vy[c];
+          vx[c] = cs * vx[c] - sn * vy[c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) x[c] = cs * x[c] - sn * y[cur][c];
+      na -= t * gg;
+      if (!DB && r < 3) fetch(r + 1, 0);
+    }
+  };
+  auto load_col = [&](auto wv, int slot, v2 (&x)[NC], v2 (&vx)[NC], T& na) {
+    const T* cx = wl + (size_t)slot * PITCH + lane_off;
+    const T* ux = vl + (size_t)slot * PITCH + lane_off;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) x[c] = *(const v2*)(cx + c * 2 * LANES);
+    if (decltype(wv)::value) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) vx[c] = *(const v2*)(ux + c * 2 * LANES);
+    }
+    na = nrm[slot];
+  };
+  auto store_col = [&](auto wv, int slot, const v2 (&x)[NC], const v2 (&vx)[NC], T na) {
+    T* cx = wl + (size_t)slot * PITCH + lane_off;
+    T* ux = vl + (size_t)slot * PITCH + lane_off;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) *(v2*)(cx + c * 2 * LANES) = x[c];
+    if (decltype(wv)::value) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) *(v2*)(ux + c * 2 * LANES) = vx[c];
+    }
+    if (g == 0) nrm[slot] = na;
+  };
+  // the whole schedule once per mode (wv: V accumulated), so that the W-only instance holds no V registers at all
+  auto run_local = [&](auto wv) {
+    const int nsb = b >> 2;  // sub-blocks per block = waves of the workgroup
+    const int pi = proc & 3;
+    v2 x[NC], vx[NC];
+    T na = 0;
+    {
+      load_col(wv, proc, x, vx, na);
+      for (int s = 0; s < nsb; ++s) {
+        int m = wave + s;
+        if (m >= nsb) m -= nsb;
+        inner4(wv, x, vx, na, b + 4 * m);
+        __syncthreads();
+      }
+      store_col(wv, proc, x, vx, na);
+      __syncthreads();
+    }
+    if (within) {
+      const int n_even = nsb + (nsb & 1), halfn = n_even >> 1;
+      const int real = (nsb & 1) ? halfn - 1 : halfn;  // meetings per block and round (one pair holds the dummy when nsb is odd)
+      const int side = real > 0 ? wave / real : 2, jj = real > 0 ? wave - side * real : 0;
+      for (int t_ = 0; t_ < n_even - 1; ++t_) {
+        if (side < 2) {
+          int pa = -1, pb = -1, cnt = 0;
+          for (int j = 0; j < halfn; ++j) {
+            int p_, q_;
+            tournament_pair(n_even, t_, j, p_, q_);
+            if (q_ < nsb) {  // p_ < q_
+              if (cnt == jj) {
+                pa = p_;
+                pb = q_;
+              }
+              ++cnt;
+            }
+          }
+          if (pa >= 0) {
+            const int sa = side * b + 4 * pa + pi;
+            load_col(wv, sa, x, vx, na);
+            inner4(wv, x, vx, na, side * b + 4 * pb);
+            store_col(wv, sa, x, vx, na);
+          }
+        }
+        __syncthreads();
+      }
+      // inside the sub-blocks: processors 0, 1 of wave k take sub-block k of P, processors 2, 3 that of Q
+      {
+        const int base = (pi >> 1) * b + 4 * wave;
+#pragma unroll
+        for (int t_ = 0; t_ < 3; ++t_) {
+          int p_, q_;
+          tournament_pair(4, t_, pi & 1, p_, q_);
+          round(base + p_, base + q_);
+          asm volatile("" ::: "memory");
+        }
+      }
+      __syncthreads();
+    }
+  };
+  if (local && LANES == 16 && (b & 3) == 0) {
+    if (with_v)
+      run_local(std::true_type{});
+    else
+      run_local(std::false_type{});
+  } else {
   // ---- cross rounds: every column of P meets every column of Q ----
   // Processor i keeps column P[i] (and its V column, and its squared norm) in registers for all b rounds: only the Q
   // column of a round crosses LDS.
@@ -410,6 +598,7 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
       __syncthreads();
     }
   }
+  }  // ring schedule
   if (my_rot) flag[0] = 1;
   if (my_big) flag[1] = 1;
   const long long ts3 = wall_clock64();

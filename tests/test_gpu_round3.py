@@ -349,3 +349,33 @@ def test_non_finite_support_points_never_become_neighbours_and_do_not_slow_the_s
     assert nreg == nreg_ref == 0
     assert np.max(np.abs(g_bad - g_ref)) <= 1e-9 * np.abs(g_ref).max()
     assert t_bad < 5.0 * t_ref + 0.5, (t_bad, t_ref)
+
+
+# ---- multi-workgroup Jacobi: the wave-local sub-block schedule against the ring schedule and the oracle ---------------
+# (jacobi_mc_kernels.hpp: same pairs per sweep, different order; widths chosen so that the block width b is and is not a
+#  multiple of four, the sub-block count is odd and even, and the last sub-block is ragged)
+@pytest.mark.parametrize("force_v", ["0", "1"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_jacobi_wave_local_schedule_matches_ring_schedule_and_oracle(ctx, monkeypatch, dtype, force_v):
+    rng = np.random.default_rng(31)
+    f64 = dtype == np.float64
+    m, n = 1200, 600
+    a = (rng.standard_normal((m, n)) * (0.996 ** np.arange(n))).astype(dtype)
+    monkeypatch.setenv("CORRLA_JMC_FORCE_V", force_v)
+    for l in (96, 97, 101, 109, 117, 125, 133, 138, 141, 150, 163, 171, 200, 233, 266, 288):  # l << n: f32 stays determined
+        p = 10
+        k = l - p
+        om = rng.standard_normal((n, l)).astype(dtype)
+        uo, so, vto = orc.random_svd(a.astype(np.float64), k, 2, p, omega=om.astype(np.float64))
+        res = {}
+        for local in ("1", "0"):
+            monkeypatch.setenv("CORRLA_JMC_LOCAL", local)
+            u, s, vt = ctx.rsvd(a, k, 2, p, omega=om)
+            res[local] = (u, s, vt)
+            assert np.max(np.abs(s.astype(np.float64) - so)) <= (1e-10 if f64 else 1e-4) * so[0, 0], (l, local)
+            assert abs(orc.relerr(a, u, s, vt) - orc.relerr(a, uo, so, vto)) <= (1e-9 if f64 else 1e-5), (l, local)
+            assert orth_err(u) < (1e-11 if f64 else 2e-4) and orth_err(vt.T) < (1e-11 if f64 else 2e-4), (l, local)
+            assert np.all(np.diff(s.ravel()) <= 0) and np.all(s >= 0), (l, local)
+        s1, s0 = res["1"][1].astype(np.float64), res["0"][1].astype(np.float64)
+        assert np.max(np.abs(s1 - s0)) <= (1e-12 if f64 else 2e-5) * so[0, 0], l
+    monkeypatch.delenv("CORRLA_JMC_LOCAL")
