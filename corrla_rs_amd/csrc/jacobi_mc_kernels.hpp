@@ -17,6 +17,12 @@
 // hang.  Squared column norms are recomputed at the start of every step and updated analytically in between
 // (a' = a - t g, b' = b + t g), so a round needs one dot product.
 //
+// Round 3: the rounds of a step are no longer one ring over the whole block (one workgroup barrier per round) but run
+// in SUB-BLOCKS of four columns, one per wave, with a barrier only when the sub-blocks move between waves (see
+// "wave-local schedule" in jmc_step_kernel; CORRLA_JMC_LOCAL=0 restores the ring).  Measured at l = 138 f32 (b = 24,
+// six waves): 937 shader cycles per round against 1220, 13.5 us per step against 17.2; what is left is the VALU issue
+// of ~85 instructions per wave and round (two of the four SIMDs carry two waves), not the barrier.
+//
 // Columns whose squared norm is below floor2 = l eps^2 (the core is pre-scaled to max |entry| in [1, 2)) are numerically
 // zero: every rotation against a large column re-injects rounding noise of their own size into them, so they would
 // never test orthogonal and the iteration would never end (a core with sigma_min / sigma_max below eps: 40 sweeps without
@@ -395,9 +401,14 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
       const int sy = sb0 + ((pi + r) & 3);
       T* cy = wl + (size_t)sy * PITCH + lane_off;
       T* uy = vl + (size_t)sy * PITCH + lane_off;
-      v2 acc = x[0] * y[cur][0];
+      v2 acc = x[0] * y[cur][0], acc2 = {0, 0};  // two chains: the dot product sits on the critical path of the round
+      if (NC > 1) acc2 = x[1] * y[cur][1];
 #pragma unroll
-      for (int c = 1; c < NC; ++c) acc += x[c] * y[cur][c];
+      for (int c = 2; c < NC; c += 2) {
+        acc += x[c] * y[cur][c];
+        if (c + 1 < NC) acc2 += x[c + 1] * y[cur][c + 1];
+      }
+      acc += acc2;
       const T gg = jmc_sum<LANES>(acc[0] + acc[1]);
       T cs, sn, t, rel;
       const bool rot = jmc_rotation_flat(na, nb[cur], gg, tol, floor2, cs, sn, rel, t);

@@ -17,7 +17,7 @@ def run(dtype, m, n, k, p, local, max_b):
     for _ in range(3):
         ctx.rsvd(a, k, 2, p, seed=3)
     tm = ctx.last_timings() if hasattr(ctx, "last_timings") else None
-    os.environ["CORRLA_DEBUG"] = "1"
+    os.environ["CORRLA_DEBUG"] = os.environ.get("DEBUG_LEVEL", "1")
     sys.stderr.write(f"== local={local} max_b={max_b} {dtype} l={k + p} timings={tm}\n")
     sys.stderr.flush()
     ctx.rsvd(a, k, 2, p, seed=3)
