@@ -204,34 +204,37 @@ __global__ __launch_bounds__(1024) void jmc_init_kernel(const T* __restrict__ c,
   }
 }
 
-// jacobi_rotation without its early exits: the same arithmetic in a straight line, (cs, sn, t) = (1, 0, 0) when the pair
-// is left alone (a column below floor2, |cos| <= tol, or the overflow guard) -- applying that "rotation" is exact.
-__device__ __forceinline__ bool jmc_rotation_flat(float a, float b, float g, float tol, float floor2, float& cs, float& sn,
-                                                  float& rel, float& t) {
-  const float rs = __builtin_amdgcn_rsqf(a) * __builtin_amdgcn_rsqf(b);
-  rel = fabsf(g) * rs;
+// jacobi_rotation without its early exits: the same rotation arithmetic in a straight line, (cs, sn, t) = (1, 0, 0) when
+// the pair is left alone (a column below floor2, |cos| <= tol, or the overflow guard) -- applying that "rotation" is exact.
+// The rounds are bound by VALU issue, so the threshold tests are formed without the two reciprocal square roots of
+// |g| / sqrt(a b): g^2 > tol^2 a b.  (a, b > floor2 = l eps^2 and the core is pre-scaled to max |entry| in [1, 2), so
+// neither product leaves the normal range.)  big: the pair also exceeds tol_early.
+__device__ __forceinline__ bool jmc_rotation_flat(float a, float b, float g, float tol, float tol_early, float floor2,
+                                                  float& cs, float& sn, float& t, bool& big) {
+  const float g2 = g * g, ab = a * b;
   const float zeta = (b - a) * 0.5f * __builtin_amdgcn_rcpf(g);
   const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta);
   const float t_ = copysignf(__builtin_amdgcn_rcpf(den), zeta);
   const float c_ = __builtin_amdgcn_rsqf(1.f + t_ * t_);
   const float s_ = c_ * t_;
-  const bool ok = (a > floor2) && (b > floor2) && (rel > tol) && (fabsf(s_) <= 1.f) && (c_ <= 1.f);
+  const bool ok = (a > floor2) && (b > floor2) && (g2 > (tol * tol) * ab) && (fabsf(s_) <= 1.f) && (c_ <= 1.f);
+  big = ok && (g2 > (tol_early * tol_early) * ab);
   cs = ok ? c_ : 1.f;
   sn = ok ? s_ : 0.f;
   t = ok ? t_ : 0.f;
   return ok;
 }
-__device__ __forceinline__ bool jmc_rotation_flat(double a, double b, double g, double tol, double floor2, double& cs,
-                                                  double& sn, double& rel, double& t) {
-  const double rs = jr_rsq(a) * jr_rsq(b);
-  rel = fabs(g) * rs;
+__device__ __forceinline__ bool jmc_rotation_flat(double a, double b, double g, double tol, double tol_early, double floor2,
+                                                  double& cs, double& sn, double& t, bool& big) {
+  const double g2 = g * g, ab = a * b;
   const double zeta = (b - a) * 0.5 * jr_rcp(g);
   const double w = 1.0 + zeta * zeta;
   const double den = fabs(zeta) + w * jr_rsq(w);
   const double t_ = copysign(jr_rcp(den), zeta);
   const double c_ = jr_rsq(1.0 + t_ * t_);
   const double s_ = c_ * t_;
-  const bool ok = (a > floor2) && (b > floor2) && (rel > tol) && (fabs(s_) <= 1.0) && (c_ <= 1.0);
+  const bool ok = (a > floor2) && (b > floor2) && (g2 > (tol * tol) * ab) && (fabs(s_) <= 1.0) && (c_ <= 1.0);
+  big = ok && (g2 > (tol_early * tol_early) * ab);
   cs = ok ? c_ : 1.0;
   sn = ok ? s_ : 0.0;
   t = ok ? t_ : 0.0;
@@ -410,16 +413,22 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
       }
       acc += acc2;
       const T gg = jmc_sum<LANES>(acc[0] + acc[1]);
-      T cs, sn, t, rel;
-      const bool rot = jmc_rotation_flat(na, nb[cur], gg, tol, floor2, cs, sn, rel, t);
+      T cs, sn, t;
+      bool big;
+      const bool rot = jmc_rotation_flat(na, nb[cur], gg, tol, tol_early, floor2, cs, sn, t, big);
       my_rot |= rot ? 1 : 0;
-      my_big |= (rot && rel > tol_early) ? 1 : 0;
+      my_big |= big ? 1 : 0;
+      // late sweeps: most rounds rotate nothing -- a wave none of whose four pairs rotates skips the update (uniform)
+      const bool any = __builtin_amdgcn_ballot_w64(rot) != 0;
+      if (any) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) *(v2*)(cy + c * 2 * LANES) = sn * x[c] + cs * y[cur][c];
-      if (g == 0) nrm[sy] = nb[cur] + t * gg;
+        for (int c = 0; c < NC; ++c) *(v2*)(cy + c * 2 * LANES) = sn * x[c] + cs * y[cur][c];
+        if (g == 0) nrm[sy] = nb[cur] + t * gg;
+      }
       // the next inner round reads what other lanes of this wave have just written
       asm volatile("" ::: "memory");
       if (DB && r < 3) fetch(r + 1, cur ^ 1);
+      if (any) {
       if (WV) {
         // the V columns only receive the rotation: they are read here, behind the W traffic the next round waits for
         v2 vy[NC];
@@ -434,6 +443,7 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
 #pragma unroll
       for (int c = 0; c < NC; ++c) x[c] = cs * x[c] - sn * y[cur][c];
       na -= t * gg;
+      }
       if (!DB && r < 3) fetch(r + 1, 0);
     }
   };
