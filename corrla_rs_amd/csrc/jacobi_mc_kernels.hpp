@@ -369,7 +369,8 @@ __global__ __launch_bounds__(512) void jmc_step_kernel(T* w, T* v, int b, int nb
   const long long ts2 = wall0;
   // ---- wave-local schedule (local != 0, LANES == 16: a wave = four processors) ----------------------------------
   // The ring schedule below hands every Q column to the next processor once per round, across waves: one workgroup
-  // barrier per round, and the barrier (all waves drained + released) is about half of the ~0.55 us a round costs.
+  // barrier per round (1220 cycles per round at l = 138 f32; this schedule: 922 -- what is left is the issue of the
+  // ~85 instructions of a round with two waves on half of the SIMDs, profiles/r03_jacobi_schedules.txt).
   // Here the blocks are cut into SUB-BLOCKS of four columns, one per wave, and a wave meets a sub-block on its own:
   //   inner4: processor i keeps A[i] in registers and rotates it against B[(i + r) mod 4], r = 0..3 -- all 16 pairs of
   //           (A, B); the four B columns cross LDS, but they are touched by THIS wave only, and the LDS operations of
