@@ -367,10 +367,15 @@ def main():
         if args.gpus != 1:
             raise SystemExit("--config C5 is a single-GPU line (the sharded form is tests' fit_svd_sharded)")
         return run_c5(args)
+    # Defaults.  The untimed warm-up is sized in TIME, not in steps: the first process on a cold board measures ~3 %
+    # slower than the same command a few seconds later whatever it runs (profiles/r03_warmup_experiment.txt: C2 4.91 ms
+    # with 3 warm-up steps on a fresh box, 4.78 / 4.77 / 4.74 ms with 50 / 200 / 1000, 4.78 ms with 3 again afterwards),
+    # and under a sustained run of tall products the board's power management takes ~10 ms to settle
+    # (tools/experiments/gemm_ramp.py).  ~0.25-0.6 s of warm-up per configuration; explicit --steps / --warmup win.
     if args.steps is None:
-        args.steps = 20 if args.config != "C3" else 5
+        args.steps = {"C2": 50, "C4": 20, "C3": 5}.get(args.config, 20)
     if args.warmup is None:
-        args.warmup = 3 if args.config != "C3" else 2
+        args.warmup = {"C2": 50, "C4": 10, "C3": 5}.get(args.config, 3)
 
     import torch
     import corrla_rs_amd as cr
