@@ -111,6 +111,7 @@ class HipDev {
     no_device_chol_ = env_int("CORRLA_HOST_CHOL", 0) != 0;
     jmc_min_l_ = env_int("CORRLA_JMC_MIN_L", 96);  // below: the single-workgroup ring kernel + replay is as fast (one launch)
     jmc_max_b_ = std::min(32, std::max(2, env_int("CORRLA_JMC_MAX_B", 24)));
+    gemm_xcd_remap_ = env_int("CORRLA_GEMM_XCD", 1);
     tall_min_rows_ = env_int("CORRLA_TALL_MIN_ROWS", 65536);  // 0: the general kernels everywhere
     robust_passes_ = std::max(2, env_int("CORRLA_ROBUST_PASSES", 2));
     robust_qr_ = env_int("CORRLA_DEVICE_ROBUST_QR", 1) != 0;  // 0: the round-1 optimistic CholeskyQR2 + host-controlled repeat
@@ -1532,6 +1533,7 @@ class HipDev {
   uint64_t entropy_ = 0, calls_ = 0, calls_sharded_ = 0;
   bool no_device_chol_ = false;
   int jmc_min_l_ = 96, jmc_max_b_ = 24, jmc_local_ = 1;
+  int gemm_xcd_remap_ = 1;  // CORRLA_GEMM_XCD=0: plain block mapping in gemm_tn (see GemmArgs::xcd_remap)
   int persist_max_tiles_ = 16;
   const int* run_if_ = nullptr;
   bool phase_events_ = true;
@@ -1844,6 +1846,9 @@ class HipDev {
     }
     dim3 grid((unsigned)gx, (unsigned)cb.nblk, (unsigned)nsplit);
     check_grid(grid);
+    // gemm_tn with a few outer tiles and a long, split reduction (A^T Y at n = 512): the outer tiles of one slab on one XCD
+    a.xcd_remap = (tn && gemm_xcd_remap_ && cb.nblk == 1 && gx == outer_tiles && outer_tiles >= 2 && outer_tiles <= 32 &&
+                   nsplit >= 8) ? 1 : 0;
     a.col_base = 0;
     // Uneven column blocking: `tiles` 16-column tiles over nblk blocks need not all be cb.nt wide -- 17 tiles (l = 266)
     // are 9 + 8, not 9 + 9: the narrower blocks run the next-smaller instantiation in a second launch and skip the

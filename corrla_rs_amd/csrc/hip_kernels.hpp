@@ -136,6 +136,8 @@ struct GemmArgs {
   int outer_blocks;   // outer tiles in all; workgroup x of gridDim.x takes x, x + gridDim.x, ... (persistent launches of
                       // short reductions: the DMA ring runs on across the tile boundary, so only the first outer tile
                       // of a workgroup pays the fill latency)
+  int xcd_remap;      // gemm_tn, gridDim.y == 1: the gridDim.x outer tiles of one reduction slab run on ONE XCD (see the
+                      // kernel): they stream the same slab of the skinny operand, which then crosses the fabric once
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -220,12 +222,12 @@ __device__ __forceinline__ typename MT<T>::acc_t gemm_mma(T x, T r, typename MT<
 
 template <class T, int NT>
 __device__ __forceinline__ void store_tile(const GemmArgs<T>& g, const typename MT<T>::acc_t (&acc)[NT], int64_t outer0,
-                                           int64_t outer_limit, int64_t col0, int lane) {
+                                           int64_t outer_limit, int64_t col0, int lane, int slab_z = (int)blockIdx.z) {
   if (g.debug_flags & 8) return;  // timing-only ablation: no result stores
   T* dst;
   T sc = (T)1;
   if (g.nsplit > 1) {
-    dst = g.slab + (int64_t)blockIdx.z * g.slab_stride;
+    dst = g.slab + (int64_t)slab_z * g.slab_stride;
   } else {
     dst = g.out;
     if (g.scale) {
@@ -554,13 +556,27 @@ __global__ __launch_bounds__(64 * (NW + kLoaders)) void gemm_tn_kernel(GemmArgs<
   if (g.run_if && *g.run_if == 0) return;  // uniform over the grid
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t n_first = (int64_t)blockIdx.x * outer_tile(GW);
+  // Which (outer tile, reduction slab) this workgroup takes.  Workgroups go to the eight XCDs round-robin in linear
+  // block order (x fastest), so with the plain mapping the few outer tiles of ONE slab land on different XCDs and each
+  // pulls that slab of the skinny operand through its own L2: at 1.25M x 512 (C4) Y crossed the fabric four times
+  // (FETCH 4.16 GB for 2.96 GB algorithmic, 4.7 TB/s).  xcd_remap: of every 8 * gridDim.x consecutive workgroups, the
+  // gridDim.x that share an XCD (ids congruent mod 8) take the outer tiles of one slab.
+  int bx = (int)blockIdx.x, bz = (int)blockIdx.z;
+  if (g.xcd_remap) {
+    const int gx = (int)gridDim.x, per = 8 * gx;
+    const int lin = bx + gx * bz, grp = lin / per, r = lin - grp * per;
+    if ((grp + 1) * 8 <= (int)gridDim.z) {  // (a last, partial group of slabs keeps the plain mapping)
+      bx = r >> 3;
+      bz = grp * 8 + (r & 7);
+    }
+  }
+  const int64_t n_first = (int64_t)bx * outer_tile(GW);
   const int64_t col0 = g.col_base + (int64_t)blockIdx.y * (NT * 16);
-  const int t_begin = blockIdx.z * g.tiles_per_split;
+  const int t_begin = bz * g.tiles_per_split;
   const int t_end = min(t_begin + g.tiles_per_split, g.tiles_total);
   const int nk = t_end - t_begin;
-  // outer tiles of this workgroup: blockIdx.x, blockIdx.x + gridDim.x, ... (see gemm_nn_kernel)
-  const int nob = (g.outer_blocks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // outer tiles of this workgroup: bx, bx + gridDim.x, ... (see gemm_nn_kernel)
+  const int nob = (g.outer_blocks - bx + (int)gridDim.x - 1) / (int)gridDim.x;
   const int64_t ob_cols = (int64_t)gridDim.x * outer_tile(GW);
 
   // The loader wave (4) issues the LDS-DMA, waves 0..3 run the MFMAs (see gemm_nn).  The big tile is a
@@ -757,7 +773,7 @@ __global__ __launch_bounds__(64 * (NW + kLoaders)) void gemm_tn_kernel(GemmArgs<
     }
 #pragma unroll
     for (int mw = 0; mw < MW; ++mw)
-      store_tile<T, NT>(g, acc[mw], n0 + 16 * MW * wave + 16 * mw, g.r_cols, col0, lane);
+      store_tile<T, NT>(g, acc[mw], n0 + 16 * MW * wave + 16 * mw, g.r_cols, col0, lane, bz);
   }
 }
 
