@@ -1847,8 +1847,11 @@ class HipDev {
     dim3 grid((unsigned)gx, (unsigned)cb.nblk, (unsigned)nsplit);
     check_grid(grid);
     // gemm_tn with a few outer tiles and a long, split reduction (A^T Y at n = 512): the outer tiles of one slab on one XCD
-    a.xcd_remap = (tn && gemm_xcd_remap_ && cb.nblk == 1 && gx == outer_tiles && outer_tiles >= 2 && outer_tiles <= 32 &&
-                   nsplit >= 8) ? 1 : 0;
+    // (per launch: the kernel's remap assumes gridDim.y == 1 -- the two launches of an uneven blocking qualify one by one)
+    auto xcd_ok = [&](unsigned gy) {
+      return (tn && gemm_xcd_remap_ && gy == 1 && gx == outer_tiles && outer_tiles >= 2 && outer_tiles <= 32 && nsplit >= 8) ? 1 : 0;
+    };
+    a.xcd_remap = xcd_ok((unsigned)cb.nblk);
     a.col_base = 0;
     // Uneven column blocking: `tiles` 16-column tiles over nblk blocks need not all be cb.nt wide -- 17 tiles (l = 266)
     // are 9 + 8, not 9 + 9: the narrower blocks run the next-smaller instantiation in a second launch and skip the
@@ -1856,8 +1859,10 @@ class HipDev {
     if (uneven) {
       dim3 g1((unsigned)gx, (unsigned)n_wide, (unsigned)nsplit);
       dim3 g2((unsigned)gx, (unsigned)(cb.nblk - n_wide), (unsigned)nsplit);
+      a.xcd_remap = xcd_ok(g1.y);
       launch_nt<T>(tn, mw, cb.nt, g1, a);
       a.col_base = (int64_t)n_wide * cb.nt * 16;
+      a.xcd_remap = xcd_ok(g2.y);
       launch_nt<T>(tn, mw, cb.nt - 1, g2, a);
     } else if (alias) {
       switch (cb.nt) {

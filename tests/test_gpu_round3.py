@@ -379,3 +379,24 @@ def test_jacobi_wave_local_schedule_matches_ring_schedule_and_oracle(ctx, monkey
         s1, s0 = res["1"][1].astype(np.float64), res["0"][1].astype(np.float64)
         assert np.max(np.abs(s1 - s0)) <= (1e-12 if f64 else 2e-5) * so[0, 0], l
     monkeypatch.delenv("CORRLA_JMC_LOCAL")
+
+
+# ---- gemm_tn: the XCD-aware block mapping moves work between compute units, not bits ---------------------------------
+@pytest.mark.parametrize("dtype,m,n,k", [(np.float32, 300_000, 512, 64),    # C4's shape family: 4 outer tiles x 128 slabs
+                                         (np.float64, 40_000, 2048, 256)])  # C3's: uneven column blocking, 16 outer tiles
+def test_gemm_tn_xcd_mapping_is_bitwise_neutral(monkeypatch, torch, dtype, m, n, k):
+    import corrla_rs_amd as cr
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CORRLA_GEMM_XCD", flag)
+        c = cr.Context()
+        a = torch.empty((m, n), dtype=tdt, device="cuda")
+        c.fill_normal(a, seed=9)
+        u, s, vt = c.rsvd(a, k, 2, 10, seed=4)
+        res.append((u.cpu().numpy(), s.cpu().numpy(), vt.cpu().numpy()))
+        c.close()
+    monkeypatch.delenv("CORRLA_GEMM_XCD")
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(x, y)
+    assert np.all(np.isfinite(res[0][1])) and res[0][1][0] > 0
