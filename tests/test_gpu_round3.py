@@ -382,12 +382,16 @@ def test_jacobi_wave_local_schedule_matches_ring_schedule_and_oracle(ctx, monkey
 
 
 # ---- gemm_tn: the XCD-aware block mapping moves work between compute units, not bits ---------------------------------
-@pytest.mark.parametrize("dtype,m,n,k", [(np.float32, 300_000, 512, 64),    # C4's shape family: 4 outer tiles x 128 slabs
-                                         (np.float64, 40_000, 2048, 256)])  # C3's: uneven column blocking, 16 outer tiles
-def test_gemm_tn_xcd_mapping_is_bitwise_neutral(monkeypatch, torch, dtype, m, n, k):
+@pytest.mark.parametrize("dtype,m,n,k,split", [(np.float32, 300_000, 512, 64, None),   # C4's shape family: 4 outer tiles x 128 slabs
+                                               (np.float64, 40_000, 2048, 256, None),   # C3's: uneven column blocking, 16 outer tiles
+                                               (np.float32, 300_000, 512, 64, "20"),    # a last, partial group of slabs (20 = 2 x 8 + 4)
+                                               (np.float32, 300_000, 384, 64, "9")])    # 3 outer tiles, 9 slabs
+def test_gemm_tn_xcd_mapping_is_bitwise_neutral(monkeypatch, torch, dtype, m, n, k, split):
     import corrla_rs_amd as cr
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     res = []
+    if split:
+        monkeypatch.setenv("CORRLA_SPLIT_TN", split)
     for flag in ("1", "0"):
         monkeypatch.setenv("CORRLA_GEMM_XCD", flag)
         c = cr.Context()
